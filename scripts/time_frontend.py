@@ -1,0 +1,18 @@
+import numpy as np, torch, sys, time
+sys.path.insert(0, '.')
+from speech_to_text_amd.audio.stft import WhisperSTFT
+hours = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+n = int(57_600_000 * hours)
+fn = WhisperSTFT()
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+pcm = (torch.rand(n, device='cuda', generator=g) * 2 - 1).float()
+for _ in range(3): out = fn(pcm)
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+K = 20
+ev[0].record()
+for _ in range(K): out = fn(pcm)
+ev[1].record(); torch.cuda.synchronize()
+ms = ev[0].elapsed_time(ev[1]) / K
+alg = n * 4 + out.numel() * 4
+print(f"{hours} h: {ms*1e3:.1f} us/call  {alg/ms/1e6:.1f} GB/s algorithmic  ({alg/1e6:.1f} MB)")

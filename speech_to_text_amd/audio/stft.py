@@ -1,0 +1,178 @@
+"""MI355X drop-in for the reference's ``WhisperSTFT`` (utils/audio/stft.py:317-360).
+
+Same constructor arguments, ``__call__`` contract (1-D or [1, n] audio in, a
+[1, frames, n_mel_channels] float32 mel out), ``get_config`` / ``save`` /
+``MelSTFT.create`` behaviour.  The arithmetic runs in ``libstt_mi355x.so``;
+torch is only used to own device memory and the stream.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .mel_basis import hann_window, mel_filterbank
+
+
+class MelSTFT(object):
+    """Configuration holder with the reference's attribute names (stft.py:23-75)."""
+
+    def __init__(self, sampling_rate, n_mel_channels=80, *, win_length=1024, hop_length=256,
+                 filter_length=1024, mel_fmin=0.0, mel_fmax=8000.0, normalize_mode=None,
+                 pre_emph=0., **kwargs):
+        assert normalize_mode in (None, 'per_feature', 'all_feature')
+        self.n_mel_channels = n_mel_channels
+        self.sampling_rate = sampling_rate
+        self.win_length = win_length if win_length > 1. else int(win_length * sampling_rate)
+        self.hop_length = hop_length if hop_length > 1. else int(hop_length * sampling_rate)
+        self.filter_length = filter_length if filter_length > 1. else int(filter_length * sampling_rate)
+        self.mel_fmin = mel_fmin
+        self.mel_fmax = mel_fmax
+        self.pre_emph = pre_emph
+        self.normalize_mode = normalize_mode
+        self.mel_basis = np.expand_dims(mel_filterbank(
+            self.sampling_rate, self.filter_length, self.n_mel_channels, self.mel_fmin, self.mel_fmax
+        ), axis=0)
+
+    @property
+    def rate(self):
+        return self.sampling_rate
+
+    def get_mel_length(self, audio_length):
+        return int(math.ceil(max(self.filter_length, audio_length) / self.hop_length))
+
+    def get_audio_length(self, mel_length):
+        return mel_length * self.hop_length
+
+    def get_config(self):
+        return {
+            'class_name': self.__class__.__name__,
+            'n_mel_channels': self.n_mel_channels,
+            'sampling_rate': self.sampling_rate,
+            'win_length': self.win_length,
+            'hop_length': self.hop_length,
+            'filter_length': self.filter_length,
+            'mel_fmin': self.mel_fmin,
+            'mel_fmax': self.mel_fmax,
+            'pre_emph': self.pre_emph,
+            'normalize_mode': self.normalize_mode,
+        }
+
+    def __eq__(self, other):
+        return isinstance(other, MelSTFT) and self.get_config() == other.get_config()
+
+    def save(self, filename):
+        if not filename.endswith('.json'):
+            filename += '.json'
+        with open(filename, 'w') as f:
+            json.dump(self.get_config(), f, indent=4)
+        return filename
+
+    save_to_file = save
+
+    @classmethod
+    def load_from_file(cls, filename):
+        return MelSTFT.create(filename)
+
+    @staticmethod
+    def create(class_name, *args, **kwargs):
+        if class_name in _mel_classes:
+            return _mel_classes[class_name](*args, **kwargs)
+        elif os.path.isfile(class_name):
+            with open(class_name) as f:
+                return MelSTFT.create(**json.load(f))
+        raise ValueError("Unknown Mel STFT class !\n  Accepted : {}\n  Got : {}".format(
+            tuple(_mel_classes.keys()), class_name))
+
+
+class WhisperSTFT(MelSTFT):
+    """Whisper log-mel on the GPU.  Only the Whisper geometry (400 / 160 / 400, periodic
+    Hann, no pre-emphasis) has a kernel; other settings raise at construction."""
+
+    def __init__(self, sampling_rate=16000, n_mel_channels=80, *, win_length=400, hop_length=160,
+                 filter_length=400, mel_fmin=0.0, mel_fmax=8000.0, window='hann', periodic=True,
+                 device=None, **kwargs):
+        super().__init__(sampling_rate=sampling_rate, n_mel_channels=n_mel_channels,
+                         win_length=win_length, hop_length=hop_length, filter_length=filter_length,
+                         mel_fmin=mel_fmin, mel_fmax=mel_fmax, **kwargs)
+        if (self.win_length, self.hop_length, self.filter_length) != (400, 160, 400):
+            raise ValueError("the MI355X frontend is built for win/hop/filter = 400/160/400, got "
+                             "{}/{}/{}".format(self.win_length, self.hop_length, self.filter_length))
+        if window != 'hann' or self.pre_emph or self.normalize_mode is not None:
+            raise ValueError("only window='hann', pre_emph=0, normalize_mode=None are supported")
+        self.window = window
+        self.periodic = periodic
+        self._window = hann_window(self.win_length, periodic).astype(np.float32)
+        self._device = torch.device(device) if device is not None else None
+        self._plans = {}
+        self._lib = _lib.load()
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'window': self.window, 'periodic': self.periodic, 'to_magnitude': True})
+        return config
+
+    # -- device plumbing ---------------------------------------------------
+    def _plan(self, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in self._plans:
+            import ctypes
+            handle = ctypes.c_void_p()
+            win = np.ascontiguousarray(self._window, dtype=np.float32)
+            basis = np.ascontiguousarray(self.mel_basis[0], dtype=np.float32)
+            with torch.cuda.device(key):
+                _lib.check(self._lib.stt_logmel_plan_create(
+                    int(self.n_mel_channels),
+                    win.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                    basis.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                    ctypes.byref(handle)))
+            self._plans[key] = handle
+        return self._plans[key]
+
+    def __del__(self):
+        try:
+            for handle in self._plans.values():
+                self._lib.stt_logmel_plan_destroy(handle)
+        except Exception:
+            pass
+
+    def _as_device_audio(self, audio):
+        if isinstance(audio, torch.Tensor):
+            t = audio
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(audio, dtype=np.float32)))
+        device = self._device or (t.device if t.is_cuda else torch.device('cuda', torch.cuda.current_device()))
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+        if t.dim() == 2:
+            if t.shape[0] != 1:
+                raise ValueError("one clip per call: expected shape [n] or [1, n], got {}".format(tuple(t.shape)))
+            t = t[0]
+        if t.dim() != 1 or t.numel() == 0:
+            raise ValueError("audio must be a non-empty 1-D signal")
+        if t.data_ptr() % 16:
+            t = t.clone()
+        return t
+
+    def __call__(self, audio, **kwargs):
+        """audio: [n] or [1, n] samples in [-1, 1].  Returns a CUDA tensor
+        [1, frames, n_mel_channels] (stft.py:96-120)."""
+        return self.mel_spectrogram(audio)
+
+    def mel_spectrogram(self, audio):
+        pcm = self._as_device_audio(audio)
+        n = pcm.numel()
+        frames = self._lib.stt_logmel_num_frames(n)
+        ws_bytes = self._lib.stt_logmel_workspace_bytes(n)
+        with torch.cuda.device(pcm.device):
+            mel = torch.empty((1, frames, self.n_mel_channels), dtype=torch.float32, device=pcm.device)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=pcm.device)
+            stream = torch.cuda.current_stream(pcm.device).cuda_stream
+            _lib.check(self._lib.stt_logmel_run(
+                self._plan(pcm.device), pcm.data_ptr(), n, mel.data_ptr(), ws.data_ptr(), ws_bytes,
+                stream))
+        return mel
+
+
+_mel_classes = {'MelSTFT': MelSTFT, 'WhisperSTFT': WhisperSTFT}

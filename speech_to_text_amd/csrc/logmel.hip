@@ -1,0 +1,420 @@
+// Whisper log-mel frontend for gfx950 (MI355X).
+//
+// Replaces, for filter_length = win_length = 400 and hop_length = 160, the chain
+//   utils/audio/stft.py:238-270  STFT.transform  (reflect pad, windowed DFT as a
+//                                strided conv1d, magnitude)
+//   utils/audio/stft.py:346-360  WhisperSTFT.mel_spectrogram (drop last frame,
+//                                mel projection, log10 / clamp, global max-8,
+//                                (x+4)/4)
+// with two kernels:
+//   logmel_main      one lane = one frame.  A 256-lane workgroup owns a tile of
+//                    247 consecutive frames whose PCM span is brought into LDS
+//                    once (LDS-DMA, each sample leaves HBM once apart from a
+//                    240-sample halo per tile), the next tile's span is fetched
+//                    while the current one is transformed in registers (real
+//                    200-point DFT pair, see gen_logmel.py), and every lane
+//                    writes its own output row.  It stores z = (log10(mel)+4)/4,
+//                    the clip maximum of log10(mel) (float atomic max) and, per
+//                    wave, the minimum z.
+//   logmel_finalize  applies max(z, ((gmax-8)+4)/4) only to the 64-row segments
+//                    whose recorded minimum is below the threshold.  x -> (x+4)/4
+//                    is monotone in float arithmetic, so clamping after the
+//                    scaling gives bit-identical results to clamping before it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Park a value in / fetch it from the accumulator half of the register file.  With one
+// wave per SIMD a lane owns 256 VGPRs + 256 AGPRs; the 400 floats that live between the two
+// DFT passes do not fit in the VGPR half alone.
+__device__ __forceinline__ float park(float v) {
+  float a;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ float unpark(float a) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+
+#include "logmel_codelet.inc"
+
+#define LM_HOP 160
+#define LM_NFFT 400
+#define LM_TILE_FRAMES 247                 // frames per workgroup tile
+#define LM_ROWS (LM_TILE_FRAMES + 2)       // 160-sample rows held in LDS
+#define LM_PITCH 164                       // floats per LDS row (160 + 4 pad: 16-B aligned,
+                                           // conflict-free ds_read_b128 across lanes)
+#define LM_CHUNKS_PER_ROW 41               // 16-byte pieces per row (40 data + 1 pad)
+#define LM_LDS_BYTES 163840                // whole LDS: 160 DMA instructions x 1 KiB
+#define LM_DMA_PER_WAVE 40
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// Ordered float max through integer atomics (works for any sign).
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Issue this wave's share of the LDS-DMA that brings one tile's PCM span in.
+// LDS piece q (16 B) = row q / 41, piece q % 41 of that row; the pad piece of a
+// row re-reads the row's last data piece.  g0 = clip index of the tile's first
+// sample.  Source indices are clamped into [lo, hi_al) (both multiples of 4 away
+// from pcm[0], so every piece is a 16-byte aligned load); what lies outside is
+// repaired by patch_reflect().
+__device__ __forceinline__ void issue_tile_dma(const float* __restrict__ pcm, long origin,
+                                               long lo, long hi_al, long g0, unsigned char* lds,
+                                               int wave, int lane) {
+#pragma unroll 4
+  for (int i = 0; i < LM_DMA_PER_WAVE; ++i) {
+    const int inst = wave + 4 * i;
+    const int q = inst * 64 + lane;
+    const int r = q / LM_CHUNKS_PER_ROW;
+    int cc = q - r * LM_CHUNKS_PER_ROW;
+    cc = cc > 39 ? 39 : cc;
+    long s = g0 + (long)r * LM_HOP + 4 * cc;
+    s = s > hi_al - 4 ? hi_al - 4 : s;
+    s = s < lo ? lo : s;
+    __builtin_amdgcn_global_load_lds((glb_void*)(pcm + (s - origin)), (lds_void*)(lds + inst * 1024),
+                                     16, 0, 0);
+  }
+}
+
+// Reflect padding (np.pad mode='reflect', stft.py:251-255): the samples before
+// the clip start and after its end, as far as a valid frame can reach.
+__device__ __forceinline__ void patch_reflect(const float* __restrict__ pcm, long origin,
+                                              long n_total, long hi_al, long g0, float* lds,
+                                              int tid) {
+  if (tid < 200) {
+    {   // g in [-200, 0)  ->  x[-g]
+      const long g = -200 + tid;
+      const long i = g - g0;
+      if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
+        const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
+        lds[r * LM_PITCH + c] = pcm[-g - origin];
+      }
+    }
+  }
+  if (tid < 204) {   // g in [hi_al, hi_al + 204): the unaligned clip tail, then x[2(N-1) - g]
+    const long g = hi_al + tid;
+    const long i = g - g0;
+    if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
+      const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
+      long src = g < n_total ? g : 2 * (n_total - 1) - g;
+      src = src < origin ? origin : src;      // only reached by rows no valid frame reads
+      lds[r * LM_PITCH + c] = pcm[src - origin];
+    }
+  }
+}
+
+template <int NMELS>
+__device__ __forceinline__ void project(const float (&mag)[201], const float* __restrict__ ct,
+                                        float (&mel)[NMELS]);
+template <>
+__device__ __forceinline__ void project<80>(const float (&mag)[201], const float* __restrict__ ct,
+                                            float (&mel)[80]) { logmel_project_80(mag, ct, mel); }
+template <>
+__device__ __forceinline__ void project<128>(const float (&mag)[201], const float* __restrict__ ct,
+                                             float (&mel)[128]) { logmel_project_128(mag, ct, mel); }
+
+struct LogmelArgs {
+  const float* pcm;      // pcm[0] = sample `origin` of the clip
+  long origin;           // clip index of pcm[0]
+  long lo, hi_al;        // DMA-readable clip range [lo, hi_al): lo = origin, hi_al = origin + 4k
+  long n_total;          // clip length
+  long frame_begin;      // first frame of this piece
+  long frame_count;      // frames in this piece
+  int n_tiles;
+  const float* ct;       // constant table, LOGMEL_TABLE_LEN floats
+  float* out;            // [frame_count][NMELS], row 0 = frame_begin
+  float* piece_max;      // preset to -inf
+  float* seg_min;        // [n_tiles * 4]
+};
+
+template <int NMELS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void logmel_main(const LogmelArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM_LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* __restrict__ ct = a.ct;
+
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  issue_tile_dma(a.pcm, a.origin, a.lo, a.hi_al,
+                 (a.frame_begin + (long)tile * LM_TILE_FRAMES) * LM_HOP - 200, lds, wave, lane);
+
+  float run_max = -__builtin_inff();
+  while (tile < a.n_tiles) {
+    const long t0 = a.frame_begin + (long)tile * LM_TILE_FRAMES;
+    const long g0 = t0 * LM_HOP - 200;
+    __builtin_amdgcn_s_waitcnt(0);          // this wave's DMA pieces have landed
+    __syncthreads();                        // ... and everyone else's
+    if (g0 < 0 || g0 + (long)LM_ROWS * LM_HOP > a.hi_al) {   // block-uniform
+      patch_reflect(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
+      __syncthreads();
+    }
+
+    // pass A straight from LDS: sample n of this lane's frame sits at row tid + n/160, col n%160
+    float ag[LOGMEL_N_AG];
+    v2f sv[LOGMEL_N_SV];
+    logmel_pass_a(lds + tid * (LM_PITCH * 4), ct, ag, sv);
+    __syncthreads();                        // LDS may now be refilled
+    const int next = tile + gridDim.x;
+    if (next < a.n_tiles)
+      issue_tile_dma(a.pcm, a.origin, a.lo, a.hi_al,
+                     (a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200, lds, wave, lane);
+
+    float mag[201];
+    logmel_pass_b(ct, ag, sv, mag);
+    float mel[NMELS];
+    project<NMELS>(mag, ct, mel);
+
+    const long row = (long)tile * LM_TILE_FRAMES + tid;
+    const bool valid = tid < LM_TILE_FRAMES && row < a.frame_count;
+    float ymax = -__builtin_inff(), zmin = __builtin_inff();
+#pragma unroll
+    for (int m = 0; m < NMELS; ++m) {
+      const float y = __log10f(fmaxf(mel[m], 1e-10f));
+      ymax = fmaxf(ymax, y);
+      const float z = (y + 4.0f) * 0.25f;
+      zmin = fminf(zmin, z);
+      mel[m] = z;
+    }
+    if (valid) {
+      v4f* dst = (v4f*)(a.out + row * NMELS);
+#pragma unroll
+      for (int m = 0; m < NMELS; m += 4) dst[m / 4] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
+    } else {
+      ymax = -__builtin_inff();
+      zmin = __builtin_inff();
+    }
+    run_max = fmaxf(run_max, ymax);
+    zmin = wave_min(zmin);
+    if (lane == 0) a.seg_min[tile * 4 + wave] = zmin;
+    tile = next;
+  }
+  run_max = wave_max(run_max);
+  if (lane == 0 && run_max > -__builtin_inff()) atomic_max_float(a.piece_max, run_max);
+}
+
+// Segment s = (tile, wave) covers rows [tile*247 + 64*wave, +64) of that tile.
+__global__ __launch_bounds__(256)
+void logmel_finalize(float* __restrict__ out, long n_frames, int n_mels, int n_segments,
+                     const float* __restrict__ gmax, const float* __restrict__ seg_min) {
+  const float zc = ((*gmax - 8.0f) + 4.0f) * 0.25f;
+  for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+    if (!(seg_min[s] < zc)) continue;
+    const int tile = s >> 2, wave = s & 3;
+    long r0 = (long)tile * LM_TILE_FRAMES + 64 * wave;
+    long r1 = r0 + 64;
+    const long tile_end = (long)(tile + 1) * LM_TILE_FRAMES;
+    r1 = r1 > tile_end ? tile_end : r1;
+    r1 = r1 > n_frames ? n_frames : r1;
+    const long e0 = r0 * n_mels, e1 = r1 * n_mels;      // multiples of 4 (n_mels % 4 == 0)
+    for (long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * 256) {
+      v4f v = *(v4f*)(out + e);
+      v.x = fmaxf(v.x, zc); v.y = fmaxf(v.y, zc); v.z = fmaxf(v.z, zc); v.w = fmaxf(v.w, zc);
+      *(v4f*)(out + e) = v;
+    }
+  }
+}
+
+__global__ void logmel_init(float* piece_max) { *piece_max = -__builtin_inff(); }
+
+// ------------------------------------------------------------------ host side
+#include "../../include/stt_mi355x.h"
+#include "logmel_tables.h"
+#include "stt_common.h"
+
+struct stt_logmel_plan {
+  int n_mels;
+  int device;
+  int n_cu;
+  float* d_table;
+};
+
+static const size_t kWsHeader = 256;      // piece maximum lives in the first float
+static const size_t kWsPadPcm = 512 * sizeof(float);
+
+static int tiles_for(int64_t frames) {
+  return (int)((frames + LM_TILE_FRAMES - 1) / LM_TILE_FRAMES);
+}
+
+extern "C" {
+
+int64_t stt_logmel_num_frames(int64_t n_samples) {
+  if (n_samples < LM_NFFT) n_samples = LM_NFFT;
+  return n_samples / LM_HOP;
+}
+
+size_t stt_logmel_workspace_bytes(int64_t n_samples) {
+  const int64_t frames = stt_logmel_num_frames(n_samples);
+  size_t seg = (size_t)tiles_for(frames) * 4 * sizeof(float);
+  seg = (seg + 255) & ~(size_t)255;
+  return kWsHeader + seg + kWsPadPcm;
+}
+
+int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_basis,
+                           stt_logmel_plan** plan) {
+  if (!window || !mel_basis || !plan) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_mels != 80 && n_mels != 128)
+    return stt_fail(STT_ERR_UNSUPPORTED, "n_mels must be 80 or 128 (got %d)", n_mels);
+  const int nnz = n_mels == 80 ? LOGMEL_NNZ_80 : LOGMEL_NNZ_128;
+  const unsigned short (*nz)[2] = n_mels == 80 ? logmel_nz_80 : logmel_nz_128;
+  const int off_mel = n_mels == 80 ? LOGMEL_OFF_MEL80 : LOGMEL_OFF_MEL128;
+
+  // every non-zero of the basis must have a slot in the generated projection
+  std::vector<char> covered((size_t)201 * n_mels, 0);
+  for (int i = 0; i < nnz; ++i) covered[(size_t)nz[i][0] * n_mels + nz[i][1]] = 1;
+  for (int k = 0; k < 201; ++k)
+    for (int m = 0; m < n_mels; ++m)
+      if (mel_basis[(size_t)k * n_mels + m] != 0.0f && !covered[(size_t)k * n_mels + m])
+        return stt_fail(STT_ERR_UNSUPPORTED,
+                        "mel basis has a non-zero at (bin %d, filter %d) outside the Slaney "
+                        "16 kHz / 400-point / 0-8000 Hz structure this kernel is built for", k, m);
+
+  std::vector<float> table(LOGMEL_TABLE_LEN, 0.0f);
+  for (int i = 0; i < LOGMEL_N_FFT_CONSTS; ++i) table[LOGMEL_OFF_FFT + i] = logmel_fft_consts[i];
+  for (int i = 0; i < LM_NFFT; ++i) table[LOGMEL_OFF_WIN + i] = window[i];
+  for (int k = 0; k <= 100; ++k) {
+    const double th = 2.0 * 3.14159265358979323846 * k / 400.0;
+    table[LOGMEL_OFF_TW + 2 * k] = (float)cos(th);
+    table[LOGMEL_OFF_TW + 2 * k + 1] = (float)sin(th);
+  }
+  for (int i = 0; i < nnz; ++i)
+    table[off_mel + i] = mel_basis[(size_t)nz[i][0] * n_mels + nz[i][1]];
+
+  stt_logmel_plan* p = new stt_logmel_plan();
+  p->n_mels = n_mels;
+  STT_HIP_OR_FAIL(hipGetDevice(&p->device), delete p);
+  hipDeviceProp_t prop;
+  STT_HIP_OR_FAIL(hipGetDeviceProperties(&prop, p->device), delete p);
+  p->n_cu = prop.multiProcessorCount;
+  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table, table.size() * sizeof(float)), delete p);
+  STT_HIP_OR_FAIL(hipMemcpy(p->d_table, table.data(), table.size() * sizeof(float),
+                            hipMemcpyHostToDevice), (hipFree(p->d_table), delete p));
+  *plan = p;
+  return STT_OK;
+}
+
+void stt_logmel_plan_destroy(stt_logmel_plan* plan) {
+  if (!plan) return;
+  hipFree(plan->d_table);
+  delete plan;
+}
+
+int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t sample_origin,
+                      int64_t n_local, int64_t n_total, int64_t frame_begin, int64_t frame_count,
+                      float* d_mel, float* d_piece_max, void* d_workspace, size_t workspace_bytes,
+                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!plan || !d_pcm || !d_mel || !d_piece_max || !d_workspace)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_total < LM_NFFT)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "clip shorter than 400 samples (%lld): pad it first",
+                    (long long)n_total);
+  if (frame_begin < 0 || frame_count < 0 || frame_begin + frame_count > n_total / LM_HOP)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "frame range [%lld, +%lld) outside the clip's %lld frames",
+                    (long long)frame_begin, (long long)frame_count, (long long)(n_total / LM_HOP));
+  if (((uintptr_t)d_pcm & 15) || ((uintptr_t)d_mel & 15))
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "d_pcm and d_mel must be 16-byte aligned");
+  if (frame_count == 0) {
+    hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
+    return STT_OK;
+  }
+  // samples the frames touch inside the clip must be readable
+  long need_lo = (long)frame_begin * LM_HOP - 200, need_hi = (long)(frame_begin + frame_count - 1) * LM_HOP + 200;
+  if (need_lo < 0) need_lo = 0;
+  if (need_hi > n_total) need_hi = n_total;
+  // reflected samples come from [1, 200] and [n_total - 201, n_total - 2]
+  if (frame_begin * LM_HOP - 200 < 0 && need_hi < 201) need_hi = 201;
+  const long lo = sample_origin, hi = sample_origin + n_local < n_total ? sample_origin + n_local : n_total;
+  if (sample_origin & 3)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "sample_origin must be a multiple of 4");
+  if (sample_origin < 0 || lo > need_lo || hi < need_hi || hi - lo < 8)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT,
+                    "pcm piece [%ld, %ld) does not cover the samples [%ld, %ld) its frames read", lo, hi,
+                    need_lo, need_hi);
+  const int n_tiles = tiles_for(frame_count);
+  const size_t seg_bytes = (size_t)n_tiles * 4 * sizeof(float);
+  if (workspace_bytes < kWsHeader + seg_bytes)
+    return stt_fail(STT_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes,
+                    kWsHeader + seg_bytes);
+
+  LogmelArgs a;
+  a.pcm = d_pcm; a.origin = sample_origin; a.lo = lo; a.hi_al = lo + ((hi - lo) & ~3L);
+  a.n_total = n_total;
+  a.frame_begin = frame_begin; a.frame_count = frame_count; a.n_tiles = n_tiles;
+  a.ct = plan->d_table; a.out = d_mel; a.piece_max = d_piece_max;
+  a.seg_min = (float*)((char*)d_workspace + kWsHeader);
+  const int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
+  hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
+  if (plan->n_mels == 80)
+    hipLaunchKernelGGL(logmel_main<80>, dim3(grid), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(logmel_main<128>, dim3(grid), dim3(256), 0, stream, a);
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
+int stt_logmel_stage2(const stt_logmel_plan* plan, float* d_mel, int64_t frame_count,
+                      const float* d_clip_max, const void* d_workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!plan || !d_mel || !d_clip_max || !d_workspace)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (frame_count <= 0) return STT_OK;
+  const int n_seg = tiles_for(frame_count) * 4;
+  const int grid = n_seg < 2048 ? n_seg : 2048;
+  hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
+                     plan->n_mels, n_seg, d_clip_max,
+                     (const float*)((const char*)d_workspace + kWsHeader));
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
+int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,
+                   float* d_mel, void* d_workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!plan || !d_pcm || !d_mel || !d_workspace)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_samples <= 0) return stt_fail(STT_ERR_INVALID_ARGUMENT, "empty clip");
+  if (workspace_bytes < stt_logmel_workspace_bytes(n_samples))
+    return stt_fail(STT_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes,
+                    stt_logmel_workspace_bytes(n_samples));
+  const float* pcm = d_pcm;
+  int64_t n = n_samples;
+  if (n < LM_NFFT) {   // MelSTFT.__call__ zero-pads short clips to one window (stft.py:111-112)
+    float* pad = (float*)((char*)d_workspace + workspace_bytes - kWsPadPcm);
+    STT_HIP_OR_FAIL(hipMemsetAsync(pad, 0, kWsPadPcm, stream), (void)0);
+    STT_HIP_OR_FAIL(hipMemcpyAsync(pad, d_pcm, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice,
+                                   stream), (void)0);
+    pcm = pad;
+    n = LM_NFFT;
+  }
+  float* piece_max = (float*)d_workspace;
+  const int64_t frames = n / LM_HOP;
+  int rc = stt_logmel_stage1(plan, pcm, 0, n, n, 0, frames, d_mel, piece_max, d_workspace,
+                             workspace_bytes, stream);
+  if (rc != STT_OK) return rc;
+  return stt_logmel_stage2(plan, d_mel, frames, piece_max, d_workspace, stream);
+}
+
+}  // extern "C"
