@@ -283,3 +283,29 @@ WHISPER_TRIM_KWARGS = dict(mode="remove", threshold=-25, min_silence=0.1,
 def whisper_prepare_audio(pcm, rate=SAMPLE_RATE):
     return load_audio_like_reference(pcm, normalize=True, trim_silence=True, rate=rate,
                                      **WHISPER_TRIM_KWARGS)
+
+
+def whisper_log_mel_torch(audio, n_mels=80, threads=None):
+    """The same chain with torch-CPU float32 ops, in the reference's own formulation
+    (reflect pad -> conv1d with the [402, 1, 400] windowed basis, stride 160 ->
+    magnitude -> mel matmul -> log10 / max-8 / (x+4)/4; stft.py:238-270, 346-360).
+    Multi-threaded; this is the CPU baseline the benchmark times."""
+    import torch
+    import torch.nn.functional as Fn
+    if threads:
+        torch.set_num_threads(int(threads))
+    x = torch.as_tensor(np.asarray(audio, dtype=np.float32)).reshape(1, 1, -1)
+    if x.shape[-1] < N_FFT:
+        x = Fn.pad(x, (0, N_FFT - x.shape[-1]))
+    basis = torch.from_numpy(stft_forward_basis()).unsqueeze(1)        # [402, 1, 400]
+    mel_basis = torch.from_numpy(slaney_mel_basis(n_mels=n_mels))      # [201, n_mels]
+    x = Fn.pad(x, (N_FFT // 2, N_FFT // 2), mode="reflect")
+    ft = Fn.conv1d(x, basis, stride=HOP)                               # [1, 402, T+1]
+    cutoff = N_FFT // 2 + 1
+    re, im = ft[:, :cutoff], ft[:, cutoff:]
+    mag = torch.sqrt(re * re + im * im)[:, :, :-1].abs()               # drop last frame
+    mel = torch.matmul(mag.transpose(1, 2), mel_basis)                 # [1, T, n_mels]
+    mel = torch.log10(torch.clamp(mel, min=1e-10))
+    mel = torch.maximum(mel, mel.amax(dim=(1, 2), keepdim=True) - 8.0)
+    mel = (mel + 4.0) / 4.0
+    return mel[0].numpy()
