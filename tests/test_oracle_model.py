@@ -1,0 +1,124 @@
+"""Structural cross-check of the torch oracle against transformers' Whisper built locally
+with the same seeded random weights (exact-erf GELU on both sides).  transformers is not
+the reference; this only guards the oracle against wiring mistakes (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+
+transformers = pytest.importorskip("transformers")
+
+
+def _hf_from_oracle(dims, w):
+    cfg = transformers.WhisperConfig(
+        vocab_size=dims.n_vocab, num_mel_bins=dims.n_mels, d_model=dims.n_audio_state,
+        encoder_layers=dims.n_audio_layer, encoder_attention_heads=dims.n_audio_head,
+        decoder_layers=dims.n_text_layer, decoder_attention_heads=dims.n_text_head,
+        encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
+        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
+        activation_function="gelu", dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+        pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1,
+        suppress_tokens=None, begin_suppress_tokens=None)
+    hf = transformers.WhisperForConditionalGeneration(cfg).eval()
+    sd = {}
+    amap = {"query": "q_proj", "key": "k_proj", "value": "v_proj", "out": "out_proj"}
+    for k, v in w.items():
+        parts = k.split(".")
+        side = parts[0]
+        if k.startswith("encoder.conv"):
+            sd["model.encoder.%s.%s" % (parts[1], parts[2])] = v
+        elif k == "encoder.ln_post.weight" or k == "encoder.ln_post.bias":
+            sd["model.encoder.layer_norm." + parts[-1]] = v
+        elif k == "decoder.ln.weight" or k == "decoder.ln.bias":
+            sd["model.decoder.layer_norm." + parts[-1]] = v
+        elif k == "decoder.token_embedding.weight":
+            sd["model.decoder.embed_tokens.weight"] = v
+            sd["proj_out.weight"] = v
+        elif k == "decoder.positional_embedding":
+            sd["model.decoder.embed_positions.weight"] = v
+        else:
+            n, mod = parts[2], parts[3]
+            base = "model.%s.layers.%s." % (side, n)
+            if mod in ("attn", "cross_attn"):
+                name = "self_attn" if mod == "attn" else "encoder_attn"
+                sd[base + "%s.%s.%s" % (name, amap[parts[4]], parts[5])] = v
+            elif mod == "attn_ln":
+                sd[base + "self_attn_layer_norm." + parts[4]] = v
+            elif mod == "cross_attn_ln":
+                sd[base + "encoder_attn_layer_norm." + parts[4]] = v
+            elif mod == "mlp_ln":
+                sd[base + "final_layer_norm." + parts[4]] = v
+            elif mod == "mlp":
+                sd[base + ("fc1." if parts[4] == "0" else "fc2.") + parts[5]] = v
+    sd["model.encoder.embed_positions.weight"] = om.sinusoids(dims.n_audio_ctx, dims.n_audio_state)
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("k_proj.bias" in m for m in missing), missing
+    return hf
+
+
+def test_encoder_and_decoder_match_transformers():
+    dims = om.Dims(n_mels=80, n_audio_ctx=100, n_audio_state=64, n_audio_head=2, n_audio_layer=2,
+                   n_vocab=300, n_text_ctx=32, n_text_state=64, n_text_head=2, n_text_layer=2)
+    w = om.random_weights(dims, seed=3)
+    model = om.Whisper(dims, w, gelu_approximate="none")
+    hf = _hf_from_oracle(dims, w)
+    g = torch.Generator().manual_seed(0)
+    mel = torch.randn(2, 200, 80, generator=g)
+    tokens = torch.randint(0, 300, (2, 7), generator=g)
+    with torch.no_grad():
+        enc = model.encoder(mel)
+        enc_hf = hf.model.encoder(mel.permute(0, 2, 1)).last_hidden_state
+        assert torch.allclose(enc, enc_hf, atol=2e-4), (enc - enc_hf).abs().max()
+        logits, cache = model.decoder(tokens, model.cross_kv(enc))
+        logits_hf = hf(decoder_input_ids=tokens, encoder_outputs=(enc_hf,)).logits
+        assert torch.allclose(logits, logits_hf, atol=5e-4), (logits - logits_hf).abs().max()
+        # incremental decoding with the cache equals the full pass
+        l1, c1 = model.decoder(tokens[:, :4], model.cross_kv(enc))
+        l2, c2 = model.decoder(tokens[:, 4:5], model.cross_kv(enc), c1, 4)
+        assert torch.allclose(l2[:, 0], logits[:, 4], atol=2e-4)
+
+
+def test_greedy_and_beam_consistency():
+    dims = om.Dims(n_mels=80, n_audio_ctx=50, n_audio_state=32, n_audio_head=2, n_audio_layer=1,
+                   n_vocab=40, n_text_ctx=32, n_text_state=32, n_text_head=2, n_text_layer=1)
+    model = om.Whisper(dims, om.random_weights(dims, seed=1))
+    mel = torch.randn(2, 100, 80, generator=torch.Generator().manual_seed(2))
+    prompt = torch.tensor([[3, 4, 5], [3, 4, 5]])
+    with torch.no_grad():
+        g = om.greedy(model, mel, prompt, max_new_tokens=6, eos=39, pad=39, early_stopping=False)
+        assert g["tokens"].shape == (2, 6)
+        b1 = om.beam_search(model, mel, prompt, num_beams=1, max_new_tokens=6, eos=39, pad=39,
+                            early_stopping=False)
+        assert (b1["tokens"][:, 0] == g["tokens"]).all()       # beam width 1 is greedy
+        assert torch.allclose(b1["scores"][:, 0], g["scores"], atol=1e-5)
+        b4 = om.beam_search(model, mel, prompt, num_beams=4, num_sentences=2, max_new_tokens=6,
+                            eos=39, pad=39, early_stopping=False)
+        assert b4["tokens"].shape == (2, 2, 6)
+        assert (b4["scores"][:, 0] >= g["scores"] - 1e-5).all()  # best beam is at least as likely
+        assert (b4["scores"][:, 0] >= b4["scores"][:, 1]).all()
+    # EOS handling: lengths exclude EOS, later slots are pad
+    with torch.no_grad():
+        lg = om.greedy(model, mel, prompt, max_new_tokens=6, eos=int(g["tokens"][0, 2]), pad=0)
+    assert int(lg["lengths"][0]) <= 2
+
+
+def test_timestamp_filter_rules():
+    cfg = om.FilterConfig(remove_tokens=(1, 2), remove_tokens_first=(1, 2, 3), timestamp_begin=20,
+                          eos=10, max_initial_timestamp=1)
+    s = torch.zeros(2, 30)
+    first = om.timestamp_filter(s, torch.zeros(2, 4, dtype=torch.long), 0, cfg)
+    assert torch.isfinite(first).sum(dim=1).tolist() == [1, 1] and torch.isfinite(first[:, 20]).all()
+    gen = torch.tensor([[21, 5, 0, 0], [21, 22, 0, 0]])
+    # t=1: penultimate counts as timestamp -> timestamps suppressed; then text wins
+    a = om.timestamp_filter(s, gen, 1, cfg)
+    assert torch.isinf(a[:, 20:]).all() and torch.isinf(a[:, 1:3]).all() and torch.isfinite(a[:, 0]).all()
+    # t=2: row 0 last=text -> only remove_tokens (then timestamps, 10 of 28, outweigh any single text);
+    b = om.timestamp_filter(s, gen, 2, cfg)
+    assert torch.isinf(b[0, :20]).all() and torch.isfinite(b[0, 20:]).all()
+    # row 1 last & penultimate timestamps -> no timestamp allowed
+    assert torch.isinf(b[1, 20:]).all() and torch.isfinite(b[1, 0])
+    gen2 = torch.tensor([[5, 21, 0, 0]])
+    c = om.timestamp_filter(torch.zeros(1, 30), gen2, 2, cfg)    # last ts, penultimate text
+    assert torch.isinf(c[0, :10]).all()
