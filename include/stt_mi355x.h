@@ -78,6 +78,90 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
 int stt_logmel_stage2(const stt_logmel_plan* plan, float* d_mel, int64_t frame_count,
                       const float* d_clip_max, const void* d_workspace, void* stream);
 
+/* -------------------------------------------------------------------- engine
+ * Whisper encoder + KV-cached decoder + greedy / beam generation.  Replaces what
+ * the reference reaches through `compiled_infer` (models/interfaces/
+ * base_model.py:365-374): Transformer.infer (architectures/transformers/
+ * transformer_arch.py:1029-1065) = WhisperEncoder (whisper_arch.py:106-155) once,
+ * then generation_utils.infer (architectures/generation_utils.py:57-169).
+ * bf16 weights and GEMM inputs, fp32 accumulation, residual stream, softmax and
+ * log-softmax.
+ */
+typedef struct stt_engine stt_engine;
+
+typedef struct {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+  int32_t gelu_tanh;     /* 1: tanh GELU (Keras default, what the reference runs); 0: exact erf */
+} stt_model_config;
+
+/* Capacity: at most max_batch windows per call, max_beams sequences per window,
+ * max_text_len positions per sequence (prompt + generated, <= n_text_ctx, <= 512),
+ * max_prompt_len prompt tokens.  Nothing is allocated before stt_engine_finalize. */
+int stt_engine_create(const stt_model_config* cfg, int max_batch, int max_beams,
+                      int max_text_len, int max_prompt_len, stt_engine** engine);
+void stt_engine_destroy(stt_engine* engine);
+
+/* Weights by their OpenAI Whisper state-dict names and layouts (the source format of
+ * models/weights_converter.py): float32 host data, Linear weights [out][in], conv
+ * weights [out][in][3].  `encoder.positional_embedding` is optional (the reference
+ * recomputes the sinusoids, whisper_arch.py:93-119).  Data is copied. */
+int stt_engine_set_weight(stt_engine* engine, const char* name, const float* data, int64_t numel);
+/* Converts to bf16, uploads, allocates every buffer on the current device. */
+int stt_engine_finalize(stt_engine* engine);
+
+/* d_mel: [batch][frames][n_mels] float32 on the device, frames <= 3000; shorter
+ * windows are padded with 0.0 (BaseSTT.pad_or_trim, models/stt/base_stt.py:227-236).
+ * Runs the encoder and the per-layer cross-attention K/V of the decoder
+ * (residual_multi_head_attention.py:241-245) and keeps them in the engine.
+ * d_enc_out: optional [batch][1500][n_audio_state] float32 copy of the encoder output. */
+int stt_encode(stt_engine* engine, const float* d_mel, int batch, int frames, float* d_enc_out,
+               void* stream);
+
+/* Teacher-forced decoder pass over the last encoded batch (the `.decoder(tokens,
+ * encoder_output=...)` call of Whisper.compiled_detect_language, models/stt/
+ * whisper.py:174-186).  tokens: host [batch][n_tokens]; d_logits: device
+ * [batch][n_tokens][n_vocab] float32.  Synchronises the stream. */
+int stt_decoder_forward(stt_engine* engine, const int32_t* tokens, int batch, int n_tokens,
+                        float* d_logits, void* stream);
+
+#define STT_METHOD_GREEDY 0
+#define STT_METHOD_BEAM 1
+
+typedef struct {
+  int32_t method;                 /* STT_METHOD_* (generation_utils.py:826-831) */
+  int32_t num_beams, num_sentences;
+  int32_t max_steps;              /* new tokens at most (= max_length - prompt length) */
+  int32_t eos_token, pad_token;
+  int32_t early_stopping;
+  float temperature;              /* <= 0: not applied.  Sampling is not implemented: the result
+                                     is always the argmax / top-k of the scaled scores */
+  int32_t has_length_temperature;
+  float length_temperature;
+  int32_t has_length_power;       /* beam ranking by score / (length + 1)^length_power */
+  float length_power;
+  const int32_t* suppress;        /* host: token ids forced to -inf (logits_filter as an index
+                                     list, generation_utils.py:521-522); with timestamp_filter = 1
+                                     it is `remove_tokens` (every step but the first) */
+  int32_t n_suppress;
+  int32_t timestamp_filter;       /* 1: the Whisper rules of models/stt/whisper.py:354-416 */
+  const int32_t* suppress_first;  /* host: `remove_tokens_with_space` (first step) */
+  int32_t n_suppress_first;
+  int32_t timestamp_begin;
+  int32_t max_initial_timestamp;
+  int32_t check_every;            /* tokens between two host checks of "all finished" (0 = 8) */
+} stt_generate_params;
+
+/* Generation over the last encoded batch.  prompt: host [batch][prompt_len].
+ * out_tokens: host [batch][num_sentences][max_steps] (pad_token after the end),
+ * out_lengths: [batch][num_sentences] generated tokens without the EOS,
+ * out_scores: [batch][num_sentences] summed log-probabilities
+ * (InferenceOutput of generation_utils.py:293-300, 466-481).  num_sentences is 1 for
+ * greedy.  Synchronises the stream before returning. */
+int stt_generate(stt_engine* engine, const stt_generate_params* params, const int32_t* prompt,
+                 int batch, int prompt_len, int32_t* out_tokens, int32_t* out_lengths,
+                 float* out_scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

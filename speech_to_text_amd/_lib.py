@@ -61,4 +61,5 @@ def check(code):
 
 def exported_symbols():
     """Names this binding expects the library to export (= include/stt_mi355x.h)."""
-    return sorted(_declare(ctypes.CDLL(LIB_PATH)).keys())
+    from .engine import ENGINE_SYMBOLS
+    return sorted(list(_declare(ctypes.CDLL(LIB_PATH)).keys()) + list(ENGINE_SYMBOLS))

@@ -1,0 +1,331 @@
+// Attention kernels of the Whisper engine (gfx950), head size 64.
+//
+// Reference semantics (architectures/layers/residual_multi_head_attention.py:167-208):
+// softmax(q k^T / sqrt(64), where(mask, ., -inf)) v, computed per head.
+#include "kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(16))) float f16_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+// multiply eight packed bf16 by 1/8 (exact: a power of two)
+__device__ __forceinline__ uint4 scale8(uint4 v) {
+  uint32_t* p = (uint32_t*)&v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(p[i] << 16) * 0.125f, hi = __uint_as_float(p[i] & 0xFFFF0000u) * 0.125f;
+    p[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention (no mask), flash style, one wave = 64 queries, 32 keys per step.
+// S^T = K Q^T with v_mfma_f32_32x32x16_bf16 puts a query on each lane (column) and 16 of the 32
+// keys in its registers (the other 16 in lane ^ 32), so the softmax statistics are per lane.
+// The S^T accumulator, rounded to bf16, is directly the B operand of O^T += V^T P^T, whose k
+// order inside a 16-key step is (register j of half h) -> key 16 s + 8 (j >> 2) + 4 h + (j & 3);
+// V^T is read from a [64][t_pad] image with that same order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_encoder_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
+    const bf16_t* __restrict__ vt, int t_pad, bf16_t* __restrict__ out, int t, int heads) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 256 + wave * 64;
+  if (q0 >= t) return;
+  const int d_model = heads * 64;
+  const bf16_t* qb = q + b * batch_stride + h * 64;
+  const bf16_t* kb = k + b * batch_stride + h * 64;
+  const bf16_t* vb = vt + ((long)b * heads + h) * 64 * t_pad;
+
+  bf8_t qf[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    int qi = q0 + 32 * x + c; qi = qi < t ? qi : t - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[x][s] = __builtin_bit_cast(bf8_t, scale8(*(const uint4*)(qb + (long)qi * ld + 16 * s + 8 * hh)));
+  }
+  f16_t o[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][dt][r] = 0.f;
+  float mrun[2] = {-__builtin_inff(), -__builtin_inff()}, lrun[2] = {0.f, 0.f};
+
+  for (int key0 = 0; key0 < t; key0 += 32) {
+    bf8_t kf[4];
+    {
+      int ki = key0 + c; ki = ki < t ? ki : t - 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        kf[s] = __builtin_bit_cast(bf8_t, *(const uint4*)(kb + (long)ki * ld + 16 * s + 8 * hh));
+    }
+    bf8_t vf[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16_t* p = vb + (long)(32 * dt + c) * t_pad + key0 + 16 * s2 + 4 * hh;
+        const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 8);
+        vf[dt][s2] = __builtin_bit_cast(bf8_t, uint4{lo.x, lo.y, hi.x, hi.y});
+      }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      f16_t s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ss], qf[x][ss], s, 0, 0, 0);
+      if (key0 + 32 > t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= t) s[r] = -__builtin_inff();
+        }
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[x], mx);
+      const float alpha = __expf(mrun[x] - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); rs += s[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      lrun[x] = lrun[x] * alpha + rs;
+      mrun[x] = mnew;
+      bf8_t pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 u;
+        u.x = pack2(s[8 * s2 + 0], s[8 * s2 + 1]); u.y = pack2(s[8 * s2 + 2], s[8 * s2 + 3]);
+        u.z = pack2(s[8 * s2 + 4], s[8 * s2 + 5]); u.w = pack2(s[8 * s2 + 6], s[8 * s2 + 7]);
+        pf[s2] = __builtin_bit_cast(bf8_t, u);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[x][dt][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          o[x][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][s2], pf[s2], o[x][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int qi = q0 + 32 * x + c;
+    if (qi >= t) continue;
+    const float inv = 1.0f / lrun[x];
+    bf16_t* dst = out + ((long)b * t + qi) * d_model + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 = features 32 dt + 8 g + 4 hh + 0..3
+        uint2 p;
+        p.x = pack2(o[x][dt][4 * g] * inv, o[x][dt][4 * g + 1] * inv);
+        p.y = pack2(o[x][dt][4 * g + 2] * inv, o[x][dt][4 * g + 3] * inv);
+        *(uint2*)(dst + 32 * dt + 8 * g + 4 * hh) = p;
+      }
+  }
+}
+
+void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
+                         const bf16_t* vt, int t_pad, bf16_t* out, int batch, int t, int heads,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(attn_encoder_kernel, dim3((t + 255) / 256, heads, batch), dim3(256), 0, stream,
+                     q, k, ld, batch_stride, vt, t_pad, out, t, heads);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder self-attention over the KV cache: one wave per (sequence, head).  Position p of
+// sequence i lives in cache slot slot_of[i][p] (beam search re-links histories instead of
+// copying them; generation_utils.py:652-676 gathers the whole cache).  New tokens are appended
+// to the sequence's own slot.  Causal inside the new tokens (transformer_arch.py:186-195).
+// ---------------------------------------------------------------------------------------------
+#define SELF_MAX_LEN 512
+__global__ __launch_bounds__(64) void attn_decoder_self_kernel(const SelfAttnArgs a) {
+  __shared__ float probs[SELF_MAX_LEN];
+  __shared__ float qs[64];
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x, i = blockIdx.y;
+  const int d_model = a.heads * 64;
+  const int base = a.base_len[i];
+  const long slot_stride = (long)a.heads * a.max_len * 64;
+  bf16_t* kown = a.k_cache + (long)i * slot_stride + (long)h * a.max_len * 64;
+  bf16_t* vown = a.v_cache + (long)i * slot_stride + (long)h * a.max_len * 64;
+  for (int j = 0; j < a.s_new; ++j) {
+    const int p = base + j;
+    if (p < a.max_len) {
+      const bf16_t* row = a.qkv + (long)(i * a.s_new + j) * 3 * d_model + h * 64;
+      kown[(long)p * 64 + lane] = row[d_model + lane];
+      vown[(long)p * 64 + lane] = row[2 * d_model + lane];
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < a.s_new; ++j) {
+    const int n_keys = base + j + 1 < a.max_len ? base + j + 1 : a.max_len;
+    qs[lane] = bf2f(a.qkv[(long)(i * a.s_new + j) * 3 * d_model + h * 64 + lane]) * 0.125f;
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int p = lane; p < n_keys; p += 64) {
+      const int slot = p >= base ? i : a.slot_of[(long)i * a.max_len + p];
+      const bf16_t* kr = a.k_cache + (long)slot * slot_stride + ((long)h * a.max_len + p) * 64;
+      float s = 0.f;
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+        const uint4 u = *(const uint4*)(kr + 8 * c8);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s += __uint_as_float(w[e] << 16) * qs[8 * c8 + 2 * e];
+          s += __uint_as_float(w[e] & 0xFFFF0000u) * qs[8 * c8 + 2 * e + 1];
+        }
+      }
+      probs[p] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int p = lane; p < n_keys; p += 64) {
+      const float e = __expf(probs[p] - mx);
+      probs[p] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();
+    float acc = 0.f;
+    for (int p = 0; p < n_keys; ++p) {
+      const int slot = p >= base ? i : a.slot_of[(long)i * a.max_len + p];
+      acc += probs[p] * bf2f(a.v_cache[(long)slot * slot_stride + ((long)h * a.max_len + p) * 64 + lane]);
+    }
+    a.out[(long)(i * a.s_new + j) * d_model + h * 64 + lane] = f2bf(acc / sum);
+    __syncthreads();
+  }
+}
+
+void launch_attn_decoder_self(const SelfAttnArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_decoder_self_kernel, dim3(a.heads, a.n_seq), dim3(64), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder cross-attention: K/V of the encoder output are read once per (window, head) and step
+// for all the sequences of that window (its beams), in 1 KiB wave accesses (8 keys x 128 B).
+// Lane = (key group l >> 3, 16-byte piece l & 7).  Queries are handled CQ at a time.
+// ---------------------------------------------------------------------------------------------
+#define CQ 8
+#define CROSS_MAX_T 1536
+__global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttnArgs a) {
+  __shared__ float sc[CQ][CROSS_MAX_T];
+  __shared__ float qs[CQ][64];
+  __shared__ float red[4][CQ][64];
+  __shared__ float stat[CQ][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int piece = lane & 7, kg = lane >> 3;
+  const int h = blockIdx.x, win = blockIdx.y;
+  const int d_model = a.heads * 64;
+  const int nq_total = a.seq_per_win * a.s_new;
+  const long row0 = (long)win * nq_total;          // first query row of this window
+  const bf16_t* kb = a.k + ((long)win * a.heads + h) * a.t_enc * 64;
+  const bf16_t* vb = a.v + ((long)win * a.heads + h) * a.t_enc * 64;
+  const int T = a.t_enc;
+
+  for (int qc = 0; qc < nq_total; qc += CQ) {
+    const int nq = nq_total - qc < CQ ? nq_total - qc : CQ;
+    for (int e = tid; e < CQ * 64; e += 256) {
+      const int qi = e >> 6, d = e & 63;
+      qs[qi][d] = qi < nq ? bf2f(a.q[(row0 + qc + qi) * d_model + h * 64 + d]) * 0.125f : 0.f;
+    }
+    __syncthreads();
+    float qr[CQ][8];
+#pragma unroll
+    for (int qi = 0; qi < CQ; ++qi)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qr[qi][e] = qs[qi][8 * piece + e];
+    // scores
+    for (int key = wave * 8 + kg; key < T; key += 32) {
+      const uint4 u = *(const uint4*)(kb + (long)key * 64 + 8 * piece);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+      float kv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(w[e] << 16); kv[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+#pragma unroll
+      for (int qi = 0; qi < CQ; ++qi) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += kv[e] * qr[qi][e];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (piece == 0) sc[qi][key] = s;
+      }
+    }
+    __syncthreads();
+    // softmax statistics: wave w handles queries w, w + 4
+    for (int qi = wave; qi < nq; qi += 4) {
+      float mx = -__builtin_inff();
+      for (int p = lane; p < T; p += 64) mx = fmaxf(mx, sc[qi][p]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+      for (int p = lane; p < T; p += 64) { const float e = __expf(sc[qi][p] - mx); sc[qi][p] = e; sum += e; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (lane == 0) { stat[qi][0] = mx; stat[qi][1] = 1.0f / sum; }
+    }
+    __syncthreads();
+    // P V
+    float acc[CQ][8];
+#pragma unroll
+    for (int qi = 0; qi < CQ; ++qi)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
+    for (int key = wave * 8 + kg; key < T; key += 32) {
+      const uint4 u = *(const uint4*)(vb + (long)key * 64 + 8 * piece);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+      float vv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vv[2 * e] = __uint_as_float(w[e] << 16); vv[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+#pragma unroll
+      for (int qi = 0; qi < CQ; ++qi) {
+        const float p = sc[qi][key];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[qi][e] += p * vv[e];
+      }
+    }
+#pragma unroll
+    for (int qi = 0; qi < CQ; ++qi)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = acc[qi][e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (kg == 0) red[wave][qi][8 * piece + e] = v;
+      }
+    __syncthreads();
+    for (int e = tid; e < nq * 64; e += 256) {
+      const int qi = e >> 6, d = e & 63;
+      const float v = (red[0][qi][d] + red[1][qi][d] + red[2][qi][d] + red[3][qi][d]) * stat[qi][1];
+      a.out[(row0 + qc + qi) * d_model + h * 64 + d] = f2bf(v);
+    }
+    __syncthreads();
+  }
+}
+
+void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_decoder_cross_kernel, dim3(a.heads, a.n_win), dim3(256), 0, stream, a);
+}

@@ -1,0 +1,173 @@
+// Normalisation, embedding and layout kernels of the Whisper engine (gfx950).  All of them are
+// HBM-bound row kernels: one wave per row, 16-byte accesses.
+#include "kernels.h"
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// x += sum of pending partial sums (+ bias); out = LayerNorm(x) (keras LayerNormalization,
+// epsilon inside the square root; residual_multi_head_attention.py:220-225,
+// transformer_arch.py:480-481, 593-597).  One wave per row, d <= 64 * 4 * LN_MAX_V4.
+#define LN_MAX_V4 8
+__global__ __launch_bounds__(256) void add_layernorm_kernel(
+    float* __restrict__ x, const float* __restrict__ slabs, int n_slabs, long slab_stride,
+    const float* __restrict__ add_bias, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
+    int m, int d, float eps, int row_mul, int row_off) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int nv = d >> 2;
+  float4 v[LN_MAX_V4];
+  const long in_row = (long)row * row_mul + row_off;
+  float* xr = x + in_row * d;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      float4 t = ((const float4*)xr)[c];
+      if (n_slabs > 0) {
+        for (int s = 0; s < n_slabs; ++s) {
+          const float4 p = ((const float4*)(slabs + s * slab_stride + in_row * d))[c];
+          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        if (add_bias) {
+          const float4 b = ((const float4*)add_bias)[c];
+          t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        }
+        ((float4*)xr)[c] = t;
+      }
+      v[i] = t;
+      sum += t.x + t.y + t.z + t.w;
+    }
+  }
+  const float mean = wave_sum(sum) / d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+      sq += a * a + b * b + cc * cc + e * e;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / d + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (out_bf16) {
+        uint2 p;
+        p.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+        p.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+        ((uint2*)(out_bf16 + (long)row * d))[c] = p;
+      }
+      if (out_f32) ((float4*)(out_f32 + (long)row * d))[c] = o;
+    }
+  }
+}
+
+void launch_add_layernorm(float* x, const float* slabs, int n_slabs, long slab_stride,
+                          const float* add_bias, const float* gamma, const float* beta,
+                          bf16_t* out_bf16, float* out_f32, int m, int d, float eps,
+                          int row_mul, int row_off, hipStream_t stream) {
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((m + 3) / 4), dim3(256), 0, stream, x, slabs,
+                     n_slabs, slab_stride, add_bias, gamma, beta, out_bf16, out_f32, m, d, eps,
+                     row_mul, row_off);
+}
+
+// mel [B][frames][n_mels] fp32 -> [B][3002][n_mels] bf16: row 0 and row 3001 zero (the conv's
+// ZeroPadding1D, current_blocks.py:297-307), rows beyond `frames` zero (pad_or_trim with
+// pad_mel_value = 0, models/stt/base_stt.py:227-236).
+__global__ void pack_mel_kernel(const float* __restrict__ mel, int frames, int n_mels,
+                                bf16_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long per_b = 3002L * n_mels;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_b; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n_mels), c = (int)(i - (long)row * n_mels);
+    float v = 0.f;
+    if (row >= 1 && row <= frames && row <= 3000) v = mel[((long)b * frames + (row - 1)) * n_mels + c];
+    out[b * per_b + i] = f2bf(v);
+  }
+}
+void launch_pack_mel(const float* mel, int batch, int frames, int n_mels, bf16_t* out,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(pack_mel_kernel, dim3(240, batch), dim3(256), 0, stream, mel, frames, n_mels, out);
+}
+
+// v[b][t][h][64] -> vt[b][h][64][t_pad] through a 64 x 64 LDS tile.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long ld,
+                                                          long batch_stride, int t, int heads,
+                                                          int t_pad, bf16_t* __restrict__ vt) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int tt = t0 + r;
+    tile[r][tx] = tt < t ? v[b * batch_stride + (long)tt * ld + h * 64 + tx] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {     // r = feature, tx = time
+    const int tt = t0 + tx;
+    if (tt < t_pad) vt[(((long)b * heads + h) * 64 + r) * t_pad + tt] = tile[tx][r];
+  }
+}
+void launch_transpose_v(const bf16_t* v, long ld, long batch_stride, int batch, int t, int heads,
+                        int t_pad, bf16_t* vt, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((t_pad + 63) / 64, heads, batch), dim3(256), 0,
+                     stream, v, ld, batch_stride, t, heads, t_pad, vt);
+}
+
+// [b][t][h][64] (row stride ld) -> [b][h][t][64]
+__global__ void split_heads_kernel(const bf16_t* __restrict__ src, long ld, long batch_stride,
+                                   int t, int heads, bf16_t* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const long n16 = (long)t * heads * 8;      // 16-byte pieces per batch element
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const int piece = (int)(i & 7);
+    const long th = i >> 3;
+    const int h = (int)(th % heads);
+    const long tt = th / heads;
+    const uint4 val = *(const uint4*)(src + b * batch_stride + tt * ld + h * 64 + piece * 8);
+    *(uint4*)(dst + (((long)b * heads + h) * t + tt) * 64 + piece * 8) = val;
+  }
+}
+void launch_split_heads(const bf16_t* src, long ld, long batch_stride, int batch, int t, int heads,
+                        bf16_t* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(split_heads_kernel, dim3(512, batch), dim3(256), 0, stream, src, ld,
+                     batch_stride, t, heads, dst);
+}
+
+// token + learned position embedding, no scaling (text_transformer_arch.py:173-193).
+__global__ void embed_kernel(const int* __restrict__ tokens, const int* __restrict__ positions,
+                             const bf16_t* __restrict__ emb, const float* __restrict__ pos_emb,
+                             float* __restrict__ x, int rows, int d, int n_vocab, int n_ctx) {
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  int tok = tokens[row]; tok = tok < 0 ? 0 : (tok >= n_vocab ? n_vocab - 1 : tok);
+  int p = positions[row]; p = p < 0 ? 0 : (p >= n_ctx ? n_ctx - 1 : p);
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    x[(long)row * d + c] = bf2f(emb[(long)tok * d + c]) + pos_emb[(long)p * d + c];
+}
+void launch_embed(const int* tokens, const int* positions, const bf16_t* emb, const float* pos_emb,
+                  float* x, int rows, int d, int n_vocab, int n_ctx, hipStream_t stream) {
+  hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, stream, tokens, positions, emb,
+                     pos_emb, x, rows, d, n_vocab, n_ctx);
+}

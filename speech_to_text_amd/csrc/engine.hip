@@ -1,0 +1,570 @@
+// Whisper engine: weights, activation buffers and the encoder / decoder / generation drivers
+// behind the C ABI of include/stt_mi355x.h.  Host code only enqueues kernels (kernels.h); the
+// generation loop synchronises every `check_every` tokens to read the "all finished" flag.
+//
+// Reference call path replaced: Transformer.infer (architectures/transformers/
+// transformer_arch.py:1029-1065) = encoder once + generation_utils.infer (greedy / beam).
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "stt_common.h"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct LayerW {
+  bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  // decoder cross-attention
+  bf16_t *wq_c = nullptr, *wkv_c = nullptr, *wo_c = nullptr;
+  float *bq_c = nullptr, *bkv_c = nullptr, *bo_c = nullptr, *lncg = nullptr, *lncb = nullptr;
+};
+
+}  // namespace
+
+struct stt_engine {
+  stt_model_config cfg;
+  int max_batch = 0, max_beams = 0, max_len = 0, max_prompt = 0;
+  int device = 0, n_cu = 256;
+  bool finalized = false;
+  std::map<std::string, std::vector<float>> host_w;
+  std::vector<void*> allocs;
+
+  // weights
+  bf16_t *conv1_w = nullptr, *conv2_w = nullptr, *tok_emb = nullptr;
+  float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *pos_emb = nullptr;
+  float *enc_lng = nullptr, *enc_lnb = nullptr, *dec_lng = nullptr, *dec_lnb = nullptr;
+  int conv1_k = 0;
+  std::vector<LayerW> enc, dec;
+
+  // encoder buffers
+  bf16_t *mel_pad = nullptr, *h1_pad = nullptr, *eh = nullptr, *eqkv = nullptr, *evt = nullptr,
+         *eatt = nullptr, *ef = nullptr, *enc_out = nullptr, *kv_tmp = nullptr;
+  float* ex = nullptr;
+  std::vector<bf16_t*> cross_k, cross_v;
+  int enc_batch = 0;       // windows held by the last stt_encode
+
+  // decoder buffers
+  int max_seq = 0, max_rows = 0;
+  float *dx = nullptr, *slabs = nullptr;
+  bf16_t *dh = nullptr, *dqkv = nullptr, *datt = nullptr, *dq = nullptr, *df = nullptr;
+  std::vector<bf16_t*> self_k, self_v;
+  int *tokens_in = nullptr, *positions = nullptr;
+  GenState gs{};
+  int *d_suppress = nullptr, *d_suppress_first = nullptr;
+  int suppress_cap = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(stt_engine* e, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  STT_HIP_OR_FAIL(hipMalloc(&p, bytes), (void)0);
+  e->allocs.push_back(p);
+  *out = (T*)p;
+  return STT_OK;
+}
+
+bf16_t host_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+int upload_bf16(stt_engine* e, bf16_t** out, const std::vector<float>& v) {
+  std::vector<bf16_t> h(v.size());
+  for (size_t i = 0; i < v.size(); ++i) h[i] = host_f2bf(v[i]);
+  int rc = dev_alloc(e, out, v.size());
+  if (rc) return rc;
+  STT_HIP_OR_FAIL(hipMemcpy(*out, h.data(), h.size() * sizeof(bf16_t), hipMemcpyHostToDevice), (void)0);
+  return STT_OK;
+}
+int upload_f32(stt_engine* e, float** out, const std::vector<float>& v) {
+  int rc = dev_alloc(e, out, v.size());
+  if (rc) return rc;
+  STT_HIP_OR_FAIL(hipMemcpy(*out, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice), (void)0);
+  return STT_OK;
+}
+
+const std::vector<float>* find_w(stt_engine* e, const std::string& name, size_t numel) {
+  auto it = e->host_w.find(name);
+  if (it == e->host_w.end()) {
+    stt_fail(STT_ERR_INVALID_ARGUMENT, "weight '%s' was never set", name.c_str());
+    return nullptr;
+  }
+  if (it->second.size() != numel) {
+    stt_fail(STT_ERR_INVALID_ARGUMENT, "weight '%s' has %zu elements, expected %zu", name.c_str(),
+             it->second.size(), numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+#define GETW(var, name, numel)                      \
+  const std::vector<float>* var = find_w(e, name, numel); \
+  if (!var) return STT_ERR_INVALID_ARGUMENT;
+
+// conv weight [out][in][3] -> GEMM weight [out][kpad], k = tap * in + channel
+std::vector<float> conv_as_gemm(const std::vector<float>& w, int out, int in, int kpad) {
+  std::vector<float> g((size_t)out * kpad, 0.f);
+  for (int o = 0; o < out; ++o)
+    for (int c = 0; c < in; ++c)
+      for (int t = 0; t < 3; ++t) g[(size_t)o * kpad + t * in + c] = w[((size_t)o * in + c) * 3 + t];
+  return g;
+}
+
+std::vector<float> concat(std::initializer_list<const std::vector<float>*> parts) {
+  std::vector<float> r;
+  for (auto p : parts) r.insert(r.end(), p->begin(), p->end());
+  return r;
+}
+
+int load_layer(stt_engine* e, const std::string& p, int d, bool decoder, LayerW& L) {
+  const size_t dd = (size_t)d * d;
+  const std::vector<float> zeros(d, 0.f);
+  {
+    GETW(q, p + "attn.query.weight", dd) GETW(k, p + "attn.key.weight", dd)
+    GETW(v, p + "attn.value.weight", dd) GETW(o, p + "attn.out.weight", dd)
+    GETW(qb, p + "attn.query.bias", d) GETW(vb, p + "attn.value.bias", d)
+    GETW(ob, p + "attn.out.bias", d)
+    int rc;
+    if ((rc = upload_bf16(e, &L.wqkv, concat({q, k, v})))) return rc;
+    if ((rc = upload_f32(e, &L.bqkv, concat({qb, &zeros, vb})))) return rc;   // key has no bias
+    if ((rc = upload_bf16(e, &L.wo, *o))) return rc;
+    if ((rc = upload_f32(e, &L.bo, *ob))) return rc;
+    GETW(g1, p + "attn_ln.weight", d) GETW(b1, p + "attn_ln.bias", d)
+    GETW(g2, p + "mlp_ln.weight", d) GETW(b2, p + "mlp_ln.bias", d)
+    if ((rc = upload_f32(e, &L.ln1g, *g1)) || (rc = upload_f32(e, &L.ln1b, *b1)) ||
+        (rc = upload_f32(e, &L.ln2g, *g2)) || (rc = upload_f32(e, &L.ln2b, *b2))) return rc;
+    GETW(w1, p + "mlp.0.weight", 4 * dd) GETW(bb1, p + "mlp.0.bias", 4 * (size_t)d)
+    GETW(w2, p + "mlp.2.weight", 4 * dd) GETW(bb2, p + "mlp.2.bias", d)
+    if ((rc = upload_bf16(e, &L.w1, *w1)) || (rc = upload_f32(e, &L.b1, *bb1)) ||
+        (rc = upload_bf16(e, &L.w2, *w2)) || (rc = upload_f32(e, &L.b2, *bb2))) return rc;
+  }
+  if (decoder) {
+    GETW(q, p + "cross_attn.query.weight", dd) GETW(k, p + "cross_attn.key.weight", dd)
+    GETW(v, p + "cross_attn.value.weight", dd) GETW(o, p + "cross_attn.out.weight", dd)
+    GETW(qb, p + "cross_attn.query.bias", d) GETW(vb, p + "cross_attn.value.bias", d)
+    GETW(ob, p + "cross_attn.out.bias", d)
+    GETW(g, p + "cross_attn_ln.weight", d) GETW(b, p + "cross_attn_ln.bias", d)
+    int rc;
+    if ((rc = upload_bf16(e, &L.wq_c, *q)) || (rc = upload_f32(e, &L.bq_c, *qb)) ||
+        (rc = upload_bf16(e, &L.wkv_c, concat({k, v}))) ||
+        (rc = upload_f32(e, &L.bkv_c, concat({&zeros, vb}))) ||
+        (rc = upload_bf16(e, &L.wo_c, *o)) || (rc = upload_f32(e, &L.bo_c, *ob)) ||
+        (rc = upload_f32(e, &L.lncg, *g)) || (rc = upload_f32(e, &L.lncb, *b))) return rc;
+  }
+  return STT_OK;
+}
+
+GemmArgs gemm_args(const bf16_t* a, long lda, const bf16_t* w, const float* bias, void* out, long ldc,
+                   int m, int n, int k, int gelu_tanh) {
+  GemmArgs g{};
+  g.a = a; g.lda = lda; g.a_batch_stride = 0; g.w = w; g.bias = bias; g.out = out; g.ldc = ldc;
+  g.out_batch_stride = 0; g.pos = nullptr; g.pos_ld = 0; g.m = m; g.n = n; g.k = k; g.batch = 1;
+  g.gelu_tanh = gelu_tanh;
+  return g;
+}
+
+// y = a @ w^T (+bias) on `rows` rows: skinny kernel for decode-sized M, tiled kernel otherwise.
+// resid != null: the product is added to the fp32 residual stream; for the skinny path that
+// happens later (the partial sums stay pending in e->slabs and are consumed by the next
+// add_layernorm), *pending_slabs returns how many.
+void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const float* bias, int rows,
+           int n, int k, int epilogue, void* out, long ldc, int* pending_slabs, hipStream_t st) {
+  GemmArgs g = gemm_args(a, lda, w, bias, out, ldc, rows, n, k, e->cfg.gelu_tanh);
+  if (pending_slabs) *pending_slabs = 0;
+  if (rows <= 256) {
+    if (epilogue == EPI_RESID_F32) {
+      const int s = pick_split_k(rows, n, k, e->n_cu);
+      launch_gemm_skinny(g, -1, s, e->slabs, st);
+      *pending_slabs = s;
+    } else {
+      launch_gemm_skinny(g, epilogue, 1, nullptr, st);
+    }
+  } else {
+    launch_gemm_big(g, epilogue, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int stt_engine_create(const stt_model_config* cfg, int max_batch, int max_beams, int max_text_len,
+                      int max_prompt_len, stt_engine** out) {
+  if (!cfg || !out) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (cfg->n_audio_state % 64 || cfg->n_text_state % 64 ||
+      cfg->n_audio_state != cfg->n_audio_head * 64 || cfg->n_text_state != cfg->n_text_head * 64)
+    return stt_fail(STT_ERR_UNSUPPORTED, "head size must be 64 (state %d/%d, heads %d/%d)",
+                    cfg->n_audio_state, cfg->n_text_state, cfg->n_audio_head, cfg->n_text_head);
+  if (cfg->n_audio_state != cfg->n_text_state)
+    return stt_fail(STT_ERR_UNSUPPORTED, "encoder and decoder widths must match");
+  if (cfg->n_audio_ctx != 1500) return stt_fail(STT_ERR_UNSUPPORTED, "n_audio_ctx must be 1500");
+  if (cfg->n_mels % 8 || cfg->n_audio_state > 2048)
+    return stt_fail(STT_ERR_UNSUPPORTED, "n_mels must be a multiple of 8 and the width <= 2048");
+  if (max_batch < 1 || max_beams < 1 || max_beams > 16 || max_text_len < 2 ||
+      max_text_len > cfg->n_text_ctx || max_text_len > 512 || max_prompt_len < 1 ||
+      max_prompt_len >= max_text_len)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "bad capacity (batch %d, beams %d, text %d, prompt %d)",
+                    max_batch, max_beams, max_text_len, max_prompt_len);
+  stt_engine* e = new stt_engine();
+  e->cfg = *cfg;
+  e->max_batch = max_batch; e->max_beams = max_beams; e->max_len = max_text_len;
+  e->max_prompt = max_prompt_len;
+  hipGetDevice(&e->device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) e->n_cu = prop.multiProcessorCount;
+  *out = e;
+  return STT_OK;
+}
+
+void stt_engine_destroy(stt_engine* e) {
+  if (!e) return;
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+}
+
+int stt_engine_set_weight(stt_engine* e, const char* name, const float* data, int64_t numel) {
+  if (!e || !name || !data || numel <= 0) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine already finalized");
+  e->host_w[name].assign(data, data + numel);
+  return STT_OK;
+}
+
+int stt_engine_finalize(stt_engine* e) {
+  if (!e) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (e->finalized) return STT_OK;
+  const stt_model_config& c = e->cfg;
+  const int d = c.n_audio_state, V = c.n_vocab;
+  int rc;
+  {
+    e->conv1_k = ((3 * c.n_mels + 63) / 64) * 64;
+    GETW(w1, "encoder.conv1.weight", (size_t)d * c.n_mels * 3) GETW(b1, "encoder.conv1.bias", d)
+    GETW(w2, "encoder.conv2.weight", (size_t)d * d * 3) GETW(b2, "encoder.conv2.bias", d)
+    if ((rc = upload_bf16(e, &e->conv1_w, conv_as_gemm(*w1, d, c.n_mels, e->conv1_k))) ||
+        (rc = upload_f32(e, &e->conv1_b, *b1)) ||
+        (rc = upload_bf16(e, &e->conv2_w, conv_as_gemm(*w2, d, d, 3 * d))) ||
+        (rc = upload_f32(e, &e->conv2_b, *b2))) return rc;
+    // sinusoids (whisper_arch.py:93-104), computed in float32 like the reference
+    std::vector<float> pos((size_t)1500 * d);
+    const float inc = logf(10000.f) / (float)(d / 2 - 1);
+    for (int t = 0; t < 1500; ++t)
+      for (int i = 0; i < d / 2; ++i) {
+        const float inv = expf(-inc * (float)i);
+        const float st = (float)t * inv;
+        pos[(size_t)t * d + i] = sinf(st);
+        pos[(size_t)t * d + d / 2 + i] = cosf(st);
+      }
+    auto it = e->host_w.find("encoder.positional_embedding");   // optional override
+    if (it != e->host_w.end() && it->second.size() == pos.size()) pos = it->second;
+    if ((rc = upload_f32(e, &e->enc_pos, pos))) return rc;
+    GETW(g, "encoder.ln_post.weight", d) GETW(b, "encoder.ln_post.bias", d)
+    if ((rc = upload_f32(e, &e->enc_lng, *g)) || (rc = upload_f32(e, &e->enc_lnb, *b))) return rc;
+    GETW(te, "decoder.token_embedding.weight", (size_t)V * d)
+    GETW(pe, "decoder.positional_embedding", (size_t)c.n_text_ctx * d)
+    GETW(dg, "decoder.ln.weight", d) GETW(db, "decoder.ln.bias", d)
+    if ((rc = upload_bf16(e, &e->tok_emb, *te)) || (rc = upload_f32(e, &e->pos_emb, *pe)) ||
+        (rc = upload_f32(e, &e->dec_lng, *dg)) || (rc = upload_f32(e, &e->dec_lnb, *db))) return rc;
+  }
+  e->enc.resize(c.n_audio_layer);
+  for (int l = 0; l < c.n_audio_layer; ++l)
+    if ((rc = load_layer(e, "encoder.blocks." + std::to_string(l) + ".", d, false, e->enc[l]))) return rc;
+  e->dec.resize(c.n_text_layer);
+  for (int l = 0; l < c.n_text_layer; ++l)
+    if ((rc = load_layer(e, "decoder.blocks." + std::to_string(l) + ".", d, true, e->dec[l]))) return rc;
+  e->host_w.clear();
+
+  // ---- activation buffers
+  const size_t B = e->max_batch, T = 1500, H = c.n_audio_head;
+  const size_t R = B * T;
+  if ((rc = dev_alloc(e, &e->mel_pad, B * 3002 * c.n_mels + 4096)) ||
+      (rc = dev_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = dev_alloc(e, &e->ex, R * d)) ||
+      (rc = dev_alloc(e, &e->eh, R * d)) || (rc = dev_alloc(e, &e->eqkv, R * 3 * d)) ||
+      (rc = dev_alloc(e, &e->evt, B * H * 64 * 1536)) || (rc = dev_alloc(e, &e->eatt, R * d)) ||
+      (rc = dev_alloc(e, &e->ef, R * 4 * d)) || (rc = dev_alloc(e, &e->enc_out, R * d)) ||
+      (rc = dev_alloc(e, &e->kv_tmp, R * 2 * d))) return rc;
+  STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
+  STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
+  e->cross_k.resize(c.n_text_layer); e->cross_v.resize(c.n_text_layer);
+  for (int l = 0; l < c.n_text_layer; ++l)
+    if ((rc = dev_alloc(e, &e->cross_k[l], B * H * T * 64)) ||
+        (rc = dev_alloc(e, &e->cross_v[l], B * H * T * 64))) return rc;
+
+  e->max_seq = e->max_batch * e->max_beams;
+  e->max_rows = e->max_seq * e->max_prompt;
+  const size_t S = e->max_seq, MR = e->max_rows, L = e->max_len;
+  const size_t slab_rows = MR < 256 ? MR : 256;
+  if ((rc = dev_alloc(e, &e->dx, MR * d)) || (rc = dev_alloc(e, &e->dh, MR * d)) ||
+      (rc = dev_alloc(e, &e->dqkv, MR * 3 * d)) || (rc = dev_alloc(e, &e->datt, MR * d)) ||
+      (rc = dev_alloc(e, &e->dq, MR * d)) || (rc = dev_alloc(e, &e->df, MR * 4 * d)) ||
+      (rc = dev_alloc(e, &e->slabs, (size_t)80 * slab_rows * d)) ||
+      (rc = dev_alloc(e, &e->tokens_in, MR)) || (rc = dev_alloc(e, &e->positions, MR))) return rc;
+  e->self_k.resize(c.n_text_layer); e->self_v.resize(c.n_text_layer);
+  for (int l = 0; l < c.n_text_layer; ++l)
+    if ((rc = dev_alloc(e, &e->self_k[l], S * H * L * 64)) ||
+        (rc = dev_alloc(e, &e->self_v[l], S * H * L * 64))) return rc;
+  GenState& g = e->gs;
+  if ((rc = dev_alloc(e, &g.logits, S * V)) || (rc = dev_alloc(e, &g.generated, S * L)) ||
+      (rc = dev_alloc(e, &g.lengths, S)) || (rc = dev_alloc(e, &g.scores, S)) ||
+      (rc = dev_alloc(e, &g.finished, S)) || (rc = dev_alloc(e, &g.next_token, S)) ||
+      (rc = dev_alloc(e, &g.base_len, S)) || (rc = dev_alloc(e, &g.slot_of, S * L)) ||
+      (rc = dev_alloc(e, &g.step, 64)) || (rc = dev_alloc(e, &g.cand_val, S)) ||
+      (rc = dev_alloc(e, &g.cand_idx, S)) || (rc = dev_alloc(e, &g.generated_tmp, S * L)) ||
+      (rc = dev_alloc(e, &g.lengths_tmp, S)) || (rc = dev_alloc(e, &g.finished_tmp, S)) ||
+      (rc = dev_alloc(e, &g.slot_of_tmp, S * L)) || (rc = dev_alloc(e, &g.scores_tmp, S))) return rc;
+  g.all_finished = g.step + 16;
+  e->suppress_cap = 4096;
+  if ((rc = dev_alloc(e, &e->d_suppress, e->suppress_cap)) ||
+      (rc = dev_alloc(e, &e->d_suppress_first, e->suppress_cap))) return rc;
+  e->finalized = true;
+  return STT_OK;
+}
+
+// ------------------------------------------------------------------------------ encoder
+int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* d_enc_out,
+               void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !d_mel) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (batch < 1 || batch > e->max_batch || frames < 1 || frames > 3000)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d (max %d) / frames %d (max 3000) out of range",
+                    batch, e->max_batch, frames);
+  const stt_model_config& c = e->cfg;
+  const int d = c.n_audio_state, H = c.n_audio_head, T = 1500;
+  const int rows = batch * T;
+  const int gt = c.gelu_tanh;
+
+  launch_pack_mel(d_mel, batch, frames, c.n_mels, e->mel_pad, st);
+  {   // conv1: rows (b, t) start at mel_pad[b][t], K = 3 * n_mels (zero-padded weights beyond)
+    GemmArgs g = gemm_args(e->mel_pad, c.n_mels, e->conv1_w, e->conv1_b, e->h1_pad + d, d, 3000, d,
+                           e->conv1_k, gt);
+    g.batch = batch; g.a_batch_stride = 3002L * c.n_mels; g.out_batch_stride = 3002L * d;
+    launch_gemm_big(g, EPI_GELU_BF16, st);
+  }
+  {   // conv2, stride 2: row (b, t) starts at h1_pad[b][2 t]; + sinusoids
+    GemmArgs g = gemm_args(e->h1_pad, 2L * d, e->conv2_w, e->conv2_b, e->ex, d, T, d, 3 * d, gt);
+    g.batch = batch; g.a_batch_stride = 3002L * d; g.out_batch_stride = (long)T * d;
+    g.pos = e->enc_pos; g.pos_ld = d;
+    launch_gemm_big(g, EPI_GELU_POS_F32, st);
+  }
+  for (int l = 0; l < c.n_audio_layer; ++l) {
+    const LayerW& L = e->enc[l];
+    launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln1g, L.ln1b, e->eh, nullptr, rows, d,
+                         1e-5f, 1, 0, st);
+    launch_gemm_big(gemm_args(e->eh, d, L.wqkv, L.bqkv, e->eqkv, 3 * d, rows, 3 * d, d, gt), EPI_BF16, st);
+    launch_transpose_v(e->eqkv + 2 * d, 3L * d, (long)T * 3 * d, batch, T, H, 1536, e->evt, st);
+    launch_attn_encoder(e->eqkv, e->eqkv + d, 3L * d, (long)T * 3 * d, e->evt, 1536, e->eatt, batch,
+                        T, H, st);
+    launch_gemm_big(gemm_args(e->eatt, d, L.wo, L.bo, e->ex, d, rows, d, d, gt), EPI_RESID_F32, st);
+    launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln2g, L.ln2b, e->eh, nullptr, rows, d,
+                         1e-5f, 1, 0, st);
+    launch_gemm_big(gemm_args(e->eh, d, L.w1, L.b1, e->ef, 4 * d, rows, 4 * d, d, gt), EPI_GELU_BF16, st);
+    launch_gemm_big(gemm_args(e->ef, 4 * d, L.w2, L.b2, e->ex, d, rows, d, 4 * d, gt), EPI_RESID_F32, st);
+  }
+  launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, e->enc_lng, e->enc_lnb, e->enc_out, d_enc_out,
+                       rows, d, 1e-5f, 1, 0, st);
+  // cross-attention K/V of every decoder layer, once per window
+  for (int l = 0; l < c.n_text_layer; ++l) {
+    const LayerW& L = e->dec[l];
+    launch_gemm_big(gemm_args(e->enc_out, d, L.wkv_c, L.bkv_c, e->kv_tmp, 2 * d, rows, 2 * d, d, gt),
+                    EPI_BF16, st);
+    launch_split_heads(e->kv_tmp, 2L * d, (long)T * 2 * d, batch, T, H, e->cross_k[l], st);
+    launch_split_heads(e->kv_tmp + d, 2L * d, (long)T * 2 * d, batch, T, H, e->cross_v[l], st);
+  }
+  e->enc_batch = batch;
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One decoder pass over n_seq sequences x s_new new tokens (tokens_in / positions already on the
+// device).  last_only: logits of the last new token of every sequence -> gs.logits [n_seq][V];
+// otherwise logits of every row -> d_all_logits [rows][V].
+int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last_only,
+                 float* d_all_logits, hipStream_t st) {
+  const stt_model_config& c = e->cfg;
+  const int d = c.n_text_state, H = c.n_text_head, V = c.n_vocab;
+  const int rows = n_seq * s_new;
+  const long slab_stride = (long)rows * d;
+  launch_embed(e->tokens_in, e->positions, e->tok_emb, e->pos_emb, e->dx, rows, d, V, c.n_text_ctx, st);
+  int pend = 0;
+  const float* pend_bias = nullptr;
+  for (int l = 0; l < c.n_text_layer; ++l) {
+    const LayerW& L = e->dec[l];
+    launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, L.ln1g, L.ln1b, e->dh, nullptr,
+                         rows, d, 1e-5f, 1, 0, st);
+    dense(e, e->dh, d, L.wqkv, L.bqkv, rows, 3 * d, d, EPI_BF16, e->dqkv, 3 * d, nullptr, st);
+    SelfAttnArgs sa{e->dqkv, e->self_k[l], e->self_v[l], e->gs.slot_of, e->gs.base_len, e->datt,
+                    n_seq, s_new, H, e->max_len};
+    launch_attn_decoder_self(sa, st);
+    dense(e, e->datt, d, L.wo, L.bo, rows, d, d, EPI_RESID_F32, e->dx, d, &pend, st);
+    pend_bias = L.bo;
+    launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, L.lncg, L.lncb, e->dh, nullptr,
+                         rows, d, 1e-5f, 1, 0, st);
+    dense(e, e->dh, d, L.wq_c, L.bq_c, rows, d, d, EPI_BF16, e->dq, d, nullptr, st);
+    CrossAttnArgs ca{e->dq, e->cross_k[l], e->cross_v[l], e->datt, n_seq / seq_per_win, seq_per_win,
+                     s_new, H, 1500};
+    launch_attn_decoder_cross(ca, st);
+    dense(e, e->datt, d, L.wo_c, L.bo_c, rows, d, d, EPI_RESID_F32, e->dx, d, &pend, st);
+    pend_bias = L.bo_c;
+    launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, L.ln2g, L.ln2b, e->dh, nullptr,
+                         rows, d, 1e-5f, 1, 0, st);
+    dense(e, e->dh, d, L.w1, L.b1, rows, 4 * d, d, EPI_GELU_BF16, e->df, 4 * d, nullptr, st);
+    dense(e, e->df, 4 * d, L.w2, L.b2, rows, d, 4 * d, EPI_RESID_F32, e->dx, d, &pend, st);
+    pend_bias = L.b2;
+  }
+  if (last_only) {
+    launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, e->dec_lng, e->dec_lnb, e->dh,
+                         nullptr, n_seq, d, 1e-5f, s_new, s_new - 1, st);
+    dense(e, e->dh, d, e->tok_emb, nullptr, n_seq, V, d, EPI_F32, e->gs.logits, V, nullptr, st);
+  } else {
+    launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, e->dec_lng, e->dec_lnb, e->dh,
+                         nullptr, rows, d, 1e-5f, 1, 0, st);
+    dense(e, e->dh, d, e->tok_emb, nullptr, rows, V, d, EPI_F32, d_all_logits, V, nullptr, st);
+  }
+  return STT_OK;
+}
+
+__global__ void init_state_kernel(GenState s, int n_seq, int prompt_len, int max_len) {
+  const int i = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s.lengths[i] = prompt_len; s.scores[i] = 0.f; s.finished[i] = 0; s.next_token[i] = 0;
+    s.base_len[i] = 0;
+    if (i == 0) { *s.step = 0; *s.all_finished = 0; }
+  }
+  for (int p = threadIdx.x; p < max_len; p += blockDim.x) s.slot_of[(long)i * max_len + p] = i;
+}
+__global__ void fill_int_kernel(int* p, long n, int v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stt_decoder_forward(stt_engine* e, const int32_t* tokens, int batch, int n_tokens,
+                        float* d_logits, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !tokens || !d_logits) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (batch != e->enc_batch)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d differs from the encoded batch %d", batch, e->enc_batch);
+  if (n_tokens < 1 || n_tokens > e->max_len || batch * n_tokens > e->max_rows)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "%d tokens x %d sequences exceed the engine capacity", n_tokens, batch);
+  std::vector<int> pos((size_t)batch * n_tokens);
+  for (int b = 0; b < batch; ++b) for (int j = 0; j < n_tokens; ++j) pos[(size_t)b * n_tokens + j] = j;
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->tokens_in, tokens, pos.size() * 4, hipMemcpyHostToDevice, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->positions, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st), (void)0);
+  hipLaunchKernelGGL(init_state_kernel, dim3(batch), dim3(64), 0, st, e->gs, batch, n_tokens, e->max_len);
+  int rc = decoder_pass(e, batch, 1, n_tokens, false, d_logits, st);
+  if (rc) return rc;
+  STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);     // `pos` is a host temporary
+  return STT_OK;
+}
+
+int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* prompt, int batch,
+                 int prompt_len, int32_t* out_tokens, int32_t* out_lengths, float* out_scores,
+                 void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !p || !prompt || !out_tokens || !out_lengths || !out_scores)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (batch != e->enc_batch)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d differs from the encoded batch %d", batch, e->enc_batch);
+  const int beams = p->method == STT_METHOD_BEAM ? p->num_beams : 1;
+  const int nsent = p->method == STT_METHOD_BEAM ? p->num_sentences : 1;
+  if (p->method != STT_METHOD_GREEDY && p->method != STT_METHOD_BEAM)
+    return stt_fail(STT_ERR_UNSUPPORTED, "method %d: only greedy (0) and beam search (1) are implemented", p->method);
+  if (beams < 1 || beams > e->max_beams || nsent < 1 || nsent > beams)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "beams %d (max %d) / sentences %d out of range", beams, e->max_beams, nsent);
+  if (prompt_len < 1 || prompt_len > e->max_prompt || p->max_steps < 1 ||
+      prompt_len + p->max_steps > e->max_len)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "prompt %d + %d new tokens exceed the engine capacity (%d / %d)",
+                    prompt_len, p->max_steps, e->max_prompt, e->max_len);
+  if (p->n_suppress > e->suppress_cap || p->n_suppress_first > e->suppress_cap)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "too many suppressed tokens");
+  const int n_seq = batch * beams, V = e->cfg.n_vocab, max_steps = p->max_steps;
+  GenState& gs = e->gs;
+
+  // prompt repeated for every beam (generation_utils.py:448-451)
+  std::vector<int> tok((size_t)n_seq * prompt_len), pos((size_t)n_seq * prompt_len);
+  for (int i = 0; i < n_seq; ++i)
+    for (int j = 0; j < prompt_len; ++j) {
+      tok[(size_t)i * prompt_len + j] = prompt[(size_t)(i / beams) * prompt_len + j];
+      pos[(size_t)i * prompt_len + j] = j;
+    }
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->tokens_in, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->positions, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st), (void)0);
+  if (p->n_suppress)
+    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress, p->suppress, p->n_suppress * 4, hipMemcpyHostToDevice, st), (void)0);
+  if (p->n_suppress_first)
+    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress_first, p->suppress_first, p->n_suppress_first * 4,
+                                   hipMemcpyHostToDevice, st), (void)0);
+  hipLaunchKernelGGL(init_state_kernel, dim3(n_seq), dim3(64), 0, st, gs, n_seq, prompt_len, e->max_len);
+  hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, gs.generated, (long)n_seq * max_steps,
+                     p->pad_token);
+
+  FilterArgs f{e->d_suppress, p->n_suppress, e->d_suppress_first, p->n_suppress_first,
+               p->timestamp_filter, p->timestamp_begin, p->eos_token, p->max_initial_timestamp};
+  LogitParams lp{p->temperature, p->length_temperature, p->has_length_temperature};
+  auto select = [&](int s_new) {
+    if (p->method == STT_METHOD_BEAM)
+      launch_beam_step(gs, f, lp, batch, beams, nsent, V, max_steps, e->max_len, s_new, p->eos_token,
+                       p->pad_token, p->length_power, p->has_length_power, st);
+    else
+      launch_greedy_step(gs, f, lp, n_seq, V, max_steps, s_new, p->eos_token, p->pad_token, st);
+  };
+  int rc = decoder_pass(e, n_seq, beams, prompt_len, true, nullptr, st);
+  if (rc) return rc;
+  select(prompt_len);
+  const int check_every = p->check_every > 0 ? p->check_every : 8;
+  int steps_done = 1;
+  for (int t = 1; t < max_steps; ++t) {
+    if (p->early_stopping && (t % check_every) == 0) {
+      int fin = 0;
+      STT_HIP_OR_FAIL(hipMemcpyAsync(&fin, gs.all_finished, 4, hipMemcpyDeviceToHost, st), (void)0);
+      STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
+      if (fin) break;
+    }
+    launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
+    rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+    if (rc) return rc;
+    select(1);
+    ++steps_done;
+  }
+  (void)steps_done;
+  // results: [batch][nsent][max_steps]; lengths exclude the prompt (generation_utils.py:293-300)
+  std::vector<int> h_gen((size_t)n_seq * max_steps), h_len(n_seq);
+  std::vector<float> h_sc(n_seq);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_gen.data(), gs.generated, h_gen.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_len.data(), gs.lengths, h_len.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_sc.data(), gs.scores, h_sc.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  for (int b = 0; b < batch; ++b)
+    for (int s = 0; s < nsent; ++s) {
+      const int i = b * beams + s;
+      memcpy(out_tokens + ((size_t)b * nsent + s) * max_steps, h_gen.data() + (size_t)i * max_steps,
+             (size_t)max_steps * 4);
+      out_lengths[b * nsent + s] = h_len[i] - prompt_len;
+      out_scores[b * nsent + s] = h_sc[i];
+    }
+  return STT_OK;
+}
+
+}  // extern "C"

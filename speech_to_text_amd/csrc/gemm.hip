@@ -1,0 +1,295 @@
+// bf16 MFMA GEMMs of the Whisper engine (gfx950): C[m][n] = sum_k A[m][k] * W[n][k].
+//
+// Both kernels feed v_mfma_f32_16x16x32_bf16 with the weight fragment as the A operand and the
+// activation fragment as the B operand, so that a lane ends up with four consecutive output
+// features n of one row m: bias loads and the stores are then 8/16-byte vectors.
+//
+// Replaces the Dense / Conv1D calls of the reference model (keras.layers.Dense in
+// architectures/layers/residual_multi_head_attention.py:108-126 and
+// architectures/transformers/transformer_arch.py:259-266, Conv1D of the encoder stem
+// architectures/transformers/whisper_arch.py:121-136; a stride-s 'valid' Conv1D over zero-padded
+// rows is a GEMM whose A rows overlap: row stride = s * channels, K = 3 * channels).
+#include "kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ float gelu_f(float x, int tanh_form) {
+  if (tanh_form) {
+    // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+  }
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-M kernel: 128 x 128 x 64 block tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA tiles.
+// Global -> registers -> LDS with the next tile's loads in flight during the MFMAs; LDS rows are
+// 128 B with their 16-byte pieces XOR-swizzled by (row & 7) so fragment reads spread over banks.
+// ---------------------------------------------------------------------------------------------
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 64
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (GB_BM + GB_BN) * GB_BK * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GB_BM, n0 = blockIdx.x * GB_BN;
+  const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
+  const bf16_t* __restrict__ W = g.w;
+  const int M = g.m, N = g.n, K = g.k;
+  const int nk = K / GB_BK;
+
+  constexpr int kStage = (GB_BM + GB_BN) * GB_BK * 2, kBOff = GB_BM * GB_BK * 2;
+
+  uint4 ra[4], rb[4];
+  long a_off[4], b_off[4];
+  int s_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
+    a_off[i] = (long)gm * g.lda + ch * 8;
+    b_off[i] = (long)gn * K + ch * 8;
+    s_off[i] = row * 128 + ((ch ^ (row & 7)) << 4);
+  }
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *(const uint4*)(A + a_off[i] + (long)kt * GB_BK);
+      rb[i] = *(const uint4*)(W + b_off[i] + (long)kt * GB_BK);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(smem + buf * kStage + s_off[i]) = ra[i];
+      *(uint4*)(smem + buf * kStage + kBOff + s_off[i]) = rb[i];
+    }
+  };
+
+  f4_t acc[4][4];   // [tn][tm]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf8_t wf[4], af[4];
+      const int ch = ks * 4 + fg;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rw = wn * 64 + t * 16 + fr;
+        wf[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + cur * kStage + kBOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
+        const int rm = wm * 64 + t * 16 + fr;
+        af[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + cur * kStage + rm * 128 + ((ch ^ (rm & 7)) << 4)));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
+  const long out_base = (long)blockIdx.z * g.out_batch_stride;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = n0 + wn * 64 + tn * 16 + 4 * fg;
+      if (n >= N) continue;
+      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+      const int nv = N - n < 4 ? N - n : 4;
+      if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += g.bias[n + r];
+      }
+      if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+      }
+      const long o = out_base + (long)m * g.ldc + n;
+      if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+        bf16_t* out = (bf16_t*)g.out;
+        if (nv == 4 && ((o & 3) == 0)) {
+          uint2 p;
+          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)(out + o) = p;
+        } else {
+          for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
+        }
+      } else {
+        float* out = (float*)g.out;
+        if (EPI == EPI_GELU_POS_F32) {
+          for (int r = 0; r < nv; ++r) v[r] += g.pos[(long)m * g.pos_ld + n + r];
+        }
+        if (EPI == EPI_RESID_F32) {
+          for (int r = 0; r < nv; ++r) out[o + r] += v[r];
+        } else {
+          for (int r = 0; r < nv; ++r) out[o + r] = v[r];
+        }
+      }
+    }
+  }
+}
+
+void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
+  dim3 grid((g.n + GB_BN - 1) / GB_BN, (g.m + GB_BM - 1) / GB_BM, g.batch > 0 ? g.batch : 1);
+  switch (epilogue) {
+    case EPI_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_BF16>, grid, dim3(256), 0, stream, g); break;
+    case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, stream, g); break;
+    case EPI_RESID_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_RESID_F32>, grid, dim3(256), 0, stream, g); break;
+    case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_POS_F32>, grid, dim3(256), 0, stream, g); break;
+    default: hipLaunchKernelGGL(gemm_big_kernel<EPI_F32>, grid, dim3(256), 0, stream, g); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-M kernel (decode): every wave owns 16 output features and streams their weight rows
+// straight from HBM into registers, 128 contiguous bytes per row per step (lane group g reads
+// the 16-byte pieces 2g and 2g+1; the activation fragment uses the same k order).  Activations
+// (M x K, a few hundred KB at most) come from L2.  blockIdx.y selects a K slice (split-K).
+// ---------------------------------------------------------------------------------------------
+template <int MT, int EPI>   // MT = ceil(M / 16)
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int k_per_split,
+                                                          float* __restrict__ slabs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  const int M = g.m, N = g.n, K = g.k;
+  if (n0 >= N) return;
+  int wn = n0 + fr; wn = wn < N ? wn : N - 1;
+  const int kbeg = blockIdx.y * k_per_split;
+  const bf16_t* __restrict__ wrow = g.w + (long)wn * K + kbeg + 16 * fg;
+  const bf16_t* __restrict__ arow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int m = t * 16 + fr; m = m < M ? m : M - 1;
+    arow[t] = g.a + (long)m * g.lda + kbeg + 16 * fg;
+  }
+  f4_t acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = k_per_split / 64;
+#pragma unroll 2
+  for (int s = 0; s < nsteps; ++s) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+    const u4_t w0 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64));
+    const u4_t w1 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64 + 8));
+    const bf8_t wf0 = __builtin_bit_cast(bf8_t, w0), wf1 = __builtin_bit_cast(bf8_t, w1);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64));
+      const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64 + 8));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, a0, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, a1, acc[t], 0, 0, 0);
+    }
+  }
+
+  const int n = n0 + 4 * fg;
+  if (n >= N) return;
+  const int nv = N - n < 4 ? N - n : 4;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = t * 16 + fr;
+    if (m >= M) continue;
+    float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+    if (slabs) {
+      float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
+      for (int r = 0; r < nv; ++r) o[r] = v[r];
+      continue;
+    }
+    if (g.bias) for (int r = 0; r < nv; ++r) v[r] += g.bias[n + r];
+    if (EPI == EPI_GELU_BF16) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+    const long o = (long)m * g.ldc + n;
+    if (EPI == EPI_F32) {
+      float* out = (float*)g.out;
+      for (int r = 0; r < nv; ++r) out[o + r] = v[r];
+    } else {
+      bf16_t* out = (bf16_t*)g.out;
+      if (nv == 4 && ((o & 3) == 0)) {
+        uint2 p;
+        p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *(uint2*)(out + o) = p;
+      } else {
+        for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+int pick_split_k(int m, int n, int k, int n_cu) {
+  const int col_blocks = (n + 63) / 64;
+  const int steps = k / 64;
+  int best = 1;
+  for (int s = 1; s <= steps; ++s) {
+    if (steps % s) continue;
+    if (steps / s < 2) break;              // at least 128 of K per block
+    best = s;
+    if ((long)col_blocks * s >= 2L * n_cu) break;
+  }
+  (void)m;
+  return best;
+}
+
+template <int MT>
+static void launch_skinny_mt(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+                             hipStream_t stream) {
+  dim3 grid((g.n + 63) / 64, split_k, 1);
+  const int kps = g.k / split_k;
+  float* sl = split_k > 1 || epilogue < 0 ? slabs : nullptr;
+  if (sl) {
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+  } else if (epilogue == EPI_GELU_BF16) {
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_GELU_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+  } else if (epilogue == EPI_F32) {
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+  } else {
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+  }
+}
+
+// epilogue < 0: always write raw partial sums to slabs (even with split_k == 1).
+void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+                        hipStream_t stream) {
+  const int mt = (g.m + 15) / 16;
+  switch (mt) {
+    case 1: launch_skinny_mt<1>(g, epilogue, split_k, slabs, stream); break;
+    case 2: launch_skinny_mt<2>(g, epilogue, split_k, slabs, stream); break;
+    case 3: launch_skinny_mt<3>(g, epilogue, split_k, slabs, stream); break;
+    case 4: launch_skinny_mt<4>(g, epilogue, split_k, slabs, stream); break;
+    case 5: case 6: launch_skinny_mt<6>(g, epilogue, split_k, slabs, stream); break;
+    case 7: case 8: launch_skinny_mt<8>(g, epilogue, split_k, slabs, stream); break;
+    case 9: case 10: launch_skinny_mt<10>(g, epilogue, split_k, slabs, stream); break;
+    case 11: case 12: launch_skinny_mt<12>(g, epilogue, split_k, slabs, stream); break;
+    default: launch_skinny_mt<16>(g, epilogue, split_k, slabs, stream); break;
+  }
+}

@@ -1,0 +1,329 @@
+// Token selection kernels: logits processing, greedy argmax, beam top-k and state reorder.
+//
+// Restates architectures/generation_utils.py:195-278 (greedy body), :333-438 (beam body),
+// :484-548 (process_logits, select_next_token) and the opt-in Whisper logits filter
+// models/stt/whisper.py:354-416, fused so that the [n_seq, V] logits are read, not rewritten,
+// wherever possible.  All per-step scalars (step counter, lengths, finished flags) live in
+// device memory so that one captured graph can be replayed for every token.
+#include "kernels.h"
+
+#define NEG_INF (-__builtin_inff())
+
+struct RowMask {           // per sequence: scores outside [lo, hi) are -inf
+  int lo, hi;
+};
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// Scales the row in place (temperature, length temperature), writes -inf at suppressed tokens
+// and returns the range mask of the timestamp rules.  Every thread of the block calls it.
+__device__ RowMask prepare_row(float* __restrict__ row, int n_vocab, const FilterArgs& f,
+                               const LogitParams& p, int length, const int* __restrict__ gen_row,
+                               int t, float* sh) {
+  const int tid = threadIdx.x;
+  float mul = 1.0f;
+  if (p.temperature > 0.f) mul = 1.0f / p.temperature;
+  float lmul = 1.0f;
+  if (p.has_length_temperature) lmul = powf((float)(length + 1), p.length_temperature);
+  if (p.temperature > 0.f || p.has_length_temperature) {
+    for (int i = tid; i < n_vocab; i += 256) {
+      float v = row[i];
+      if (p.temperature > 0.f) v = v / p.temperature;
+      if (p.has_length_temperature) v = v * lmul;
+      row[i] = v;
+    }
+  }
+  (void)mul;
+  RowMask m{0, n_vocab};
+  if (!f.timestamps) {
+    for (int i = tid; i < f.n_suppress; i += 256) {
+      const int tok = f.suppress[i];
+      if (tok >= 0 && tok < n_vocab) row[tok] = NEG_INF;
+    }
+    __syncthreads();
+    return m;
+  }
+  if (t == 0) {          // only the first timestamp may start a window (whisper.py:355-367)
+    for (int i = tid; i < f.n_suppress_first; i += 256) {
+      const int tok = f.suppress_first[i];
+      if (tok >= 0 && tok < n_vocab) row[tok] = NEG_INF;
+    }
+    m.lo = f.timestamp_begin;
+    if (f.max_initial_timestamp > 0) m.hi = min(n_vocab, f.timestamp_begin + f.max_initial_timestamp);
+    __syncthreads();
+    return m;
+  }
+  for (int i = tid; i < f.n_suppress; i += 256) {
+    const int tok = f.suppress[i];
+    if (tok >= 0 && tok < n_vocab) row[tok] = NEG_INF;
+  }
+  const bool last_ts = gen_row[t - 1] >= f.timestamp_begin;
+  const bool pen_ts = t < 2 ? true : gen_row[t - 2] >= f.timestamp_begin;
+  if (last_ts && !pen_ts) m.lo = f.eos;                 // must close the pair (or stop)
+  if (last_ts && pen_ts) m.hi = f.timestamp_begin;      // no third timestamp in a row
+  __syncthreads();
+  // if the timestamps together outweigh every single text token, sample a timestamp:
+  // logsumexp(logp[ts:]) > max(logp[:ts]); the log-softmax constant cancels.
+  float mt = NEG_INF, ma = NEG_INF;
+  for (int i = tid; i < n_vocab; i += 256) {
+    const float v = (i < m.lo || i >= m.hi) ? NEG_INF : row[i];
+    if (i < f.timestamp_begin) mt = fmaxf(mt, v); else ma = fmaxf(ma, v);
+  }
+  mt = block_max(mt, sh);
+  ma = block_max(ma, sh);
+  float se = 0.f;
+  if (ma > NEG_INF)
+    for (int i = max(f.timestamp_begin, m.lo) + tid; i < m.hi; i += 256) se += __expf(row[i] - ma);
+  se = block_sum(se, sh);
+  const float ts_lse = ma > NEG_INF ? ma + __logf(se) : NEG_INF;
+  if (ts_lse > mt) m.lo = max(m.lo, f.timestamp_begin);
+  return m;
+}
+
+// max / first argmax / logsumexp of the masked row
+__device__ void row_stats(const float* __restrict__ row, RowMask m, float* sh, int* shi,
+                          float& out_max, int& out_arg, float& out_lse) {
+  const int tid = threadIdx.x;
+  float mx = NEG_INF;
+  int arg = 0x7fffffff;
+  for (int i = m.lo + tid; i < m.hi; i += 256) {
+    const float v = row[i];
+    if (v > mx) { mx = v; arg = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ov > mx || (ov == mx && oa < arg)) { mx = ov; arg = oa; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { sh[tid >> 6] = mx; shi[tid >> 6] = arg; }
+  __syncthreads();
+  mx = sh[0]; arg = shi[0];
+  for (int w = 1; w < 4; ++w)
+    if (sh[w] > mx || (sh[w] == mx && shi[w] < arg)) { mx = sh[w]; arg = shi[w]; }
+  float se = 0.f;
+  for (int i = m.lo + tid; i < m.hi; i += 256) se += __expf(row[i] - mx);
+  se = block_sum(se, sh);
+  out_max = mx; out_arg = arg; out_lse = mx + __logf(se);
+}
+
+__global__ __launch_bounds__(256) void greedy_step_kernel(const GenState s, const FilterArgs f,
+                                                          const LogitParams p, int n_vocab,
+                                                          int max_steps, int s_new, int eos,
+                                                          int pad) {
+  __shared__ float sh[4];
+  __shared__ int shi[4];
+  const int i = blockIdx.x;
+  const int t = *s.step;
+  float* row = s.logits + (long)i * n_vocab;
+  const RowMask m = prepare_row(row, n_vocab, f, p, s.lengths[i], s.generated + (long)i * max_steps, t, sh);
+  float mx, lse; int arg;
+  row_stats(row, m, sh, shi, mx, arg, lse);
+  if (threadIdx.x == 0) {
+    const int was_finished = s.finished[i];
+    const int tok = was_finished ? pad : arg;
+    if (!was_finished) s.scores[i] += mx - lse;
+    const int fin = was_finished || tok == eos;
+    s.finished[i] = fin;
+    s.lengths[i] += fin ? 0 : 1;
+    if (t < max_steps) s.generated[(long)i * max_steps + t] = tok;
+    s.next_token[i] = tok;
+    s.base_len[i] += s_new;
+  }
+}
+
+__global__ void finish_step_kernel(const GenState s, int n_seq, int group, int first_n) {
+  // all_finished = every group's first `first_n` sequences are finished; step += 1
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_seq; i += blockDim.x)
+    if ((i % group) < first_n && !s.finished[i]) ok = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) { *s.all_finished = ok; *s.step += 1; }
+}
+
+__global__ void prepare_step_kernel(const GenState s, int* tokens_in, int* positions, int n_seq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seq) { tokens_in[i] = s.next_token[i]; positions[i] = s.base_len[i]; }
+}
+void launch_prepare_step(const GenState& s, int* tokens_in, int* positions, int n_seq,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(prepare_step_kernel, dim3((n_seq + 255) / 256), dim3(256), 0, stream, s,
+                     tokens_in, positions, n_seq);
+}
+
+void launch_greedy_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int n_seq,
+                        int n_vocab, int max_steps, int s_new, int eos, int pad,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(greedy_step_kernel, dim3(n_seq), dim3(256), 0, stream, s, f, p, n_vocab,
+                     max_steps, s_new, eos, pad);
+  hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(256), 0, stream, s, n_seq, 1, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam search
+// ---------------------------------------------------------------------------------------------
+// Stage A: row <- running score + (finished ? {pad: 0, else -inf} : log_softmax(filtered row)).
+__global__ __launch_bounds__(256) void beam_logprob_kernel(const GenState s, const FilterArgs f,
+                                                           const LogitParams p, int n_vocab,
+                                                           int max_steps, int pad) {
+  __shared__ float sh[4];
+  __shared__ int shi[4];
+  const int i = blockIdx.x;
+  const int t = *s.step;
+  float* row = s.logits + (long)i * n_vocab;
+  const RowMask m = prepare_row(row, n_vocab, f, p, s.lengths[i], s.generated + (long)i * max_steps, t, sh);
+  float mx, lse; int arg;
+  row_stats(row, m, sh, shi, mx, arg, lse);
+  const float base = s.scores[i];
+  const bool fin = s.finished[i];
+  for (int j = threadIdx.x; j < n_vocab; j += 256) {
+    float v;
+    if (fin) v = j == pad ? 0.f : NEG_INF;
+    else v = (j < m.lo || j >= m.hi) ? NEG_INF : row[j] - lse;
+    row[j] = base + v;
+  }
+}
+
+// Stage B: per batch element, the `beams` best of (beams * V) candidates (first step: V),
+// ranked by value / (length + 1)^length_power, ties to the lowest flat index.
+#define BEAM_MAX 16
+__global__ __launch_bounds__(256) void beam_topk_kernel(const GenState s, int beams, int n_vocab,
+                                                        float length_power, int has_length_power) {
+  __shared__ float cv[256 * BEAM_MAX];
+  __shared__ int ci[256 * BEAM_MAX];
+  __shared__ float sh[4];
+  __shared__ int shi[4];
+  __shared__ int shpos[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = *s.step;
+  const int rows = t == 0 ? 1 : beams;
+  float lv[BEAM_MAX]; int li[BEAM_MAX];
+#pragma unroll
+  for (int k = 0; k < BEAM_MAX; ++k) { lv[k] = NEG_INF; li[k] = 0x7fffffff; }
+  for (int r = 0; r < rows; ++r) {
+    const int seq = b * beams + r;
+    const float* row = s.logits + (long)seq * n_vocab;
+    float inv = 1.0f;
+    if (has_length_power) inv = 1.0f / powf((float)(s.lengths[seq] + 1), length_power);
+    for (int j = tid; j < n_vocab; j += 256) {
+      const float v = has_length_power ? row[j] * inv : row[j];
+      if (v > lv[beams - 1]) {          // insert (indices arrive in increasing order per thread)
+        int k = beams - 1;
+        while (k > 0 && v > lv[k - 1]) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; --k; }
+        lv[k] = v; li[k] = r * n_vocab + j;
+      }
+    }
+  }
+  for (int k = 0; k < beams; ++k) { cv[tid * BEAM_MAX + k] = lv[k]; ci[tid * BEAM_MAX + k] = li[k]; }
+  __syncthreads();
+  for (int sel = 0; sel < beams; ++sel) {
+    float mx = NEG_INF; int arg = 0x7fffffff, pos = -1;
+    for (int k = 0; k < beams; ++k) {
+      const float v = cv[tid * BEAM_MAX + k]; const int id = ci[tid * BEAM_MAX + k];
+      if (v > mx || (v == mx && id < arg)) { mx = v; arg = id; pos = tid * BEAM_MAX + k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(arg, o, 64);
+      const int op = __shfl_xor(pos, o, 64);
+      if (ov > mx || (ov == mx && oa < arg)) { mx = ov; arg = oa; pos = op; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { sh[tid >> 6] = mx; shi[tid >> 6] = arg; shpos[tid >> 6] = pos; }
+    __syncthreads();
+    if (tid == 0) {
+      float bm = sh[0]; int ba = shi[0], bp = shpos[0];
+      for (int w = 1; w < 4; ++w)
+        if (sh[w] > bm || (sh[w] == bm && shi[w] < ba)) { bm = sh[w]; ba = shi[w]; bp = shpos[w]; }
+      s.cand_idx[b * beams + sel] = ba;
+      s.cand_val[b * beams + sel] = bm;
+      if (bp >= 0) { cv[bp] = NEG_INF; ci[bp] = 0x7fffffff; }
+    }
+    __syncthreads();
+  }
+}
+
+// Stage C: rebuild every sequence from its parent beam (generation_utils.py:385-408, 658-676).
+__global__ __launch_bounds__(256) void beam_reorder_kernel(const GenState s, int beams, int n_vocab,
+                                                           int max_steps, int max_len, int s_new,
+                                                           int eos, int pad) {
+  const int i = blockIdx.x;                 // new sequence
+  const int b = i / beams;
+  const int t = *s.step;
+  int idx = s.cand_idx[i];
+  if (idx == 0x7fffffff || idx < 0) idx = 0;
+  const int parent = b * beams + idx / n_vocab;
+  int tok = idx % n_vocab;
+  const int old_len = s.base_len[parent];
+  for (int j = threadIdx.x; j < max_steps; j += 256)
+    s.generated_tmp[(long)i * max_steps + j] = s.generated[(long)parent * max_steps + j];
+  for (int p = threadIdx.x; p < max_len; p += 256) {
+    int v = s.slot_of[(long)parent * max_len + p];
+    if (p >= old_len && p < old_len + s_new) v = parent;   // written by the parent during this step
+    s.slot_of_tmp[(long)i * max_len + p] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int fin = s.finished[parent];
+    int len = s.lengths[parent];
+    const float score = s.logits[(long)parent * n_vocab + tok];
+    tok = fin ? pad : tok;
+    fin = fin || tok == eos;
+    len += fin ? 0 : 1;
+    s.scores_tmp[i] = score;
+    s.finished_tmp[i] = fin;
+    s.lengths_tmp[i] = len;
+    if (t < max_steps) s.generated_tmp[(long)i * max_steps + t] = tok;
+    s.next_token[i] = tok;
+  }
+}
+
+__global__ __launch_bounds__(256) void beam_commit_kernel(const GenState s, int max_steps,
+                                                          int max_len, int s_new) {
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j < max_steps; j += 256)
+    s.generated[(long)i * max_steps + j] = s.generated_tmp[(long)i * max_steps + j];
+  for (int p = threadIdx.x; p < max_len; p += 256)
+    s.slot_of[(long)i * max_len + p] = s.slot_of_tmp[(long)i * max_len + p];
+  if (threadIdx.x == 0) {
+    s.scores[i] = s.scores_tmp[i];
+    s.finished[i] = s.finished_tmp[i];
+    s.lengths[i] = s.lengths_tmp[i];
+    s.base_len[i] += s_new;
+  }
+}
+
+void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int batch,
+                      int beams, int num_sentences, int n_vocab, int max_steps, int max_len,
+                      int s_new, int eos, int pad, float length_power, int has_length_power,
+                      hipStream_t stream) {
+  const int n_seq = batch * beams;
+  hipLaunchKernelGGL(beam_logprob_kernel, dim3(n_seq), dim3(256), 0, stream, s, f, p, n_vocab,
+                     max_steps, pad);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(batch), dim3(256), 0, stream, s, beams, n_vocab,
+                     length_power, has_length_power);
+  hipLaunchKernelGGL(beam_reorder_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
+                     max_steps, max_len, s_new, eos, pad);
+  hipLaunchKernelGGL(beam_commit_kernel, dim3(n_seq), dim3(256), 0, stream, s, max_steps, max_len,
+                     s_new);
+  hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(256), 0, stream, s, n_seq, beams,
+                     num_sentences);
+}

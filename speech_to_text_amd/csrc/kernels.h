@@ -1,0 +1,142 @@
+// Device kernels of the MI355X Whisper engine: launch wrappers shared between the .hip files.
+// Conventions: activations that feed a GEMM are bf16; the residual stream is fp32; weights are
+// bf16 [N][K] (output feature major, K contiguous); every wrapper only enqueues on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+// ---------------------------------------------------------------- GEMM epilogues
+enum GemmEpilogue {
+  EPI_BF16 = 0,        // out_bf16[m][n] = acc + bias[n]
+  EPI_GELU_BF16 = 1,   // out_bf16[m][n] = gelu(acc + bias[n])
+  EPI_RESID_F32 = 2,   // out_f32[m][n] += acc + bias[n]
+  EPI_GELU_POS_F32 = 3,// out_f32[m][n] = gelu(acc + bias[n]) + pos[m][n]     (conv2 + sinusoids)
+  EPI_F32 = 4,         // out_f32[m][n] = acc (+ bias if given)
+};
+
+struct GemmArgs {
+  const bf16_t* a;     // [batch][M rows, row stride lda elements]
+  long lda;
+  long a_batch_stride; // elements
+  const bf16_t* w;     // [N][K]
+  const float* bias;   // [N] or null
+  void* out;           // bf16 or f32, row stride ldc elements
+  long ldc;
+  long out_batch_stride;
+  const float* pos;    // [M][ldc-compatible: row stride pos_ld] for EPI_GELU_POS_F32
+  long pos_ld;
+  int m, n, k;         // k % 64 == 0
+  int batch;
+  int gelu_tanh;       // 1 = tanh approximation (Keras default), 0 = exact erf
+};
+
+// Tiled MFMA GEMM for M >= a few hundred rows (encoder, prompt pass).
+void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream);
+
+// Weight-streaming GEMM for M <= 256 rows (decode steps).  split_k > 1 writes raw fp32 partial
+// sums to slabs[split_k][M][N] (no bias / activation); split_k == 1 applies the epilogue
+// (EPI_BF16, EPI_GELU_BF16 or EPI_F32).
+void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+                        hipStream_t stream);
+int pick_split_k(int m, int n, int k, int n_cu);
+
+// ---------------------------------------------------------------- normalisation / elementwise
+// x[m][d] += sum_s slabs[s][m][d] + add_bias[d] (both optional), then out = LN(x) * gamma + beta.
+// Output row r is computed from input row r * row_mul + row_off (row_mul = 1, row_off = 0 for a
+// plain pass; used to normalise only the last position of every sequence).
+void launch_add_layernorm(float* x, const float* slabs, int n_slabs, long slab_stride,
+                          const float* add_bias, const float* gamma, const float* beta,
+                          bf16_t* out_bf16, float* out_f32, int m, int d, float eps,
+                          int row_mul, int row_off, hipStream_t stream);
+// mel fp32 [B][frames<=3000][n_mels] -> bf16 [B][3002][n_mels] with one zero row before and after
+// and rows >= frames zero (pad_or_trim with 0.0).
+void launch_pack_mel(const float* mel, int batch, int frames, int n_mels, bf16_t* out,
+                     hipStream_t stream);
+// v[b][t][h][64] (row stride ld) -> vt[b][h][64][t_pad] (zero beyond t)
+void launch_transpose_v(const bf16_t* v, long ld, long batch_stride, int batch, int t, int heads,
+                        int t_pad, bf16_t* vt, hipStream_t stream);
+// x[row][d] = E[token[row]][d] + P[pos[row]][d]
+void launch_embed(const int* tokens, const int* positions, const bf16_t* emb, const float* pos_emb,
+                  float* x, int rows, int d, int n_vocab, int n_ctx, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention
+// Encoder self-attention, no mask.  q,k: [b][t][h][64] with row stride ld (q pre-scaled by the
+// kernel, 1/8); vt: [b][h][64][t_pad]; out bf16 [b][t][h*64].
+void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
+                         const bf16_t* vt, int t_pad, bf16_t* out, int batch, int t, int heads,
+                         hipStream_t stream);
+
+struct SelfAttnArgs {
+  const bf16_t* qkv;   // [rows][3*d]: q | k | v of the new tokens; rows = n_seq * s_new
+  bf16_t* k_cache;     // [n_seq][h][max_len][64]   (this layer)
+  bf16_t* v_cache;
+  const int* slot_of;  // [n_seq][max_len]: cache sequence that holds position p of sequence i
+  const int* base_len; // [n_seq]: positions already in the cache before this call
+  bf16_t* out;         // [rows][d]
+  int n_seq, s_new, heads, max_len;
+};
+// Appends the new k,v at positions base_len[i] .. +s_new-1 of sequence i (writing into slot i)
+// and attends causally over positions 0 .. base_len[i] + j for new token j.
+void launch_attn_decoder_self(const SelfAttnArgs& a, hipStream_t stream);
+
+struct CrossAttnArgs {
+  const bf16_t* q;     // [n_seq * s_new][d]
+  const bf16_t* k;     // [n_win][h][1500][64]   (this layer)
+  const bf16_t* v;
+  bf16_t* out;         // [n_seq * s_new][d]
+  int n_win, seq_per_win, s_new, heads, t_enc;
+};
+void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream);
+// k,v rows [b][t][h][64] (row stride ld, column offsets given by the pointers) -> [b][h][t][64]
+void launch_split_heads(const bf16_t* src, long ld, long batch_stride, int batch, int t, int heads,
+                        bf16_t* dst, hipStream_t stream);
+
+// ---------------------------------------------------------------- generation
+struct GenState {          // all device pointers; n_seq = batch * beams
+  float* logits;           // [n_seq][V] fp32 (last position of each sequence)
+  int* generated;          // [n_seq][max_steps]
+  int* lengths;            // [n_seq]   (prompt + generated, EOS not counted)
+  float* scores;           // [n_seq]
+  int* finished;           // [n_seq]
+  int* next_token;         // [n_seq]
+  int* base_len;           // [n_seq]   cache length
+  int* slot_of;            // [n_seq][max_len]
+  int* step;               // [1]
+  int* all_finished;       // [1]
+  // beam search scratch
+  float* cand_val;         // [batch][beams]
+  int* cand_idx;           // [batch][beams]
+  int* generated_tmp; int* lengths_tmp; int* finished_tmp; int* slot_of_tmp; float* scores_tmp;
+};
+
+struct FilterArgs {        // device pointers
+  const int* suppress;     // tokens set to -inf at every step (or at steps > 0 with timestamps)
+  int n_suppress;
+  const int* suppress_first; // timestamp filter: tokens removed at the first step
+  int n_suppress_first;
+  int timestamps;          // 1 = apply the Whisper timestamp rules
+  int timestamp_begin, eos, max_initial_timestamp;
+};
+
+struct LogitParams {
+  float temperature;       // <= 0: unused
+  float length_temperature;// 0: unused
+  int has_length_temperature;
+};
+
+// Per sequence: filter, log_softmax; greedy: argmax + state update.
+// s_new = tokens the decoder consumed in this step (prompt length at the first step, then 1).
+void launch_greedy_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int n_seq,
+                        int n_vocab, int max_steps, int s_new, int eos, int pad,
+                        hipStream_t stream);
+// tokens_in[i] = next_token[i], positions[i] = base_len[i]
+void launch_prepare_step(const GenState& s, int* tokens_in, int* positions, int n_seq,
+                         hipStream_t stream);
+// Beam: per sequence log-probs (in place in s.logits, plus running score / finished handling),
+// then per batch element top-`beams` over beams*V and the reorder of the per-sequence state.
+void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int batch,
+                      int beams, int num_sentences, int n_vocab, int max_steps, int max_len,
+                      int s_new, int eos, int pad, float length_power, int has_length_power,
+                      hipStream_t stream);

@@ -1,0 +1,211 @@
+"""Python handle on the native Whisper engine (stt_engine_* / stt_encode / stt_generate of
+include/stt_mi355x.h).  torch only owns the device tensors handed in and out."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DIM_KEYS = ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+            "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")
+
+# OpenAI Whisper checkpoints ship these sizes (architectures/transformers/whisper_arch.py:181-189,
+# 226-234 read them from `dims`)
+WHISPER_DIMS = {
+    "tiny": dict(n_mels=80, n_audio_state=384, n_audio_head=6, n_audio_layer=4, n_vocab=51865),
+    "base": dict(n_mels=80, n_audio_state=512, n_audio_head=8, n_audio_layer=6, n_vocab=51865),
+    "small": dict(n_mels=80, n_audio_state=768, n_audio_head=12, n_audio_layer=12, n_vocab=51865),
+    "medium": dict(n_mels=80, n_audio_state=1024, n_audio_head=16, n_audio_layer=24, n_vocab=51865),
+    "large-v3": dict(n_mels=128, n_audio_state=1280, n_audio_head=20, n_audio_layer=32, n_vocab=51866),
+}
+
+
+def whisper_dims(name):
+    d = dict(WHISPER_DIMS[name])
+    d.update(n_audio_ctx=1500, n_text_ctx=448, n_text_state=d["n_audio_state"],
+             n_text_head=d["n_audio_head"], n_text_layer=d["n_audio_layer"])
+    return d
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in DIM_KEYS] + [("gelu_tanh", C.c_int32)]
+
+
+class GenerateParams(C.Structure):
+    _fields_ = [
+        ("method", C.c_int32), ("num_beams", C.c_int32), ("num_sentences", C.c_int32),
+        ("max_steps", C.c_int32), ("eos_token", C.c_int32), ("pad_token", C.c_int32),
+        ("early_stopping", C.c_int32), ("temperature", C.c_float),
+        ("has_length_temperature", C.c_int32), ("length_temperature", C.c_float),
+        ("has_length_power", C.c_int32), ("length_power", C.c_float),
+        ("suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32),
+        ("timestamp_filter", C.c_int32), ("suppress_first", C.POINTER(C.c_int32)),
+        ("n_suppress_first", C.c_int32), ("timestamp_begin", C.c_int32),
+        ("max_initial_timestamp", C.c_int32), ("check_every", C.c_int32),
+    ]
+
+
+class TimestampFilter(object):
+    """Arguments of the reference's opt-in `logits_filter` (models/stt/whisper.py:354-416)."""
+
+    def __init__(self, remove_tokens, remove_tokens_with_space, timestamp_begin_idx, eos_token_idx,
+                 max_initial_timestamp=1):
+        self.remove_tokens = np.asarray(remove_tokens, np.int32)
+        self.remove_tokens_with_space = np.asarray(remove_tokens_with_space, np.int32)
+        self.timestamp_begin_idx = int(timestamp_begin_idx)
+        self.eos_token_idx = int(eos_token_idx)
+        self.max_initial_timestamp = int(max_initial_timestamp)
+
+
+class WhisperEngine(object):
+    def __init__(self, dims, weights, max_batch=1, max_beams=1, max_text_len=256, max_prompt_len=4,
+                 gelu_tanh=True, device=None):
+        self._lib = _lib.load()
+        _declare(self._lib)
+        self.dims = {k: int(dims[k]) for k in DIM_KEYS}
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.max_batch, self.max_beams = int(max_batch), int(max_beams)
+        self.max_text_len, self.max_prompt_len = int(max_text_len), int(max_prompt_len)
+        cfg = ModelConfig(gelu_tanh=1 if gelu_tanh else 0, **self.dims)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.stt_engine_create(C.byref(cfg), self.max_batch, self.max_beams,
+                                                   self.max_text_len, self.max_prompt_len,
+                                                   C.byref(self._h)))
+            for name, value in weights.items():
+                arr = value.detach().cpu().float().numpy() if isinstance(value, torch.Tensor) else value
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                _lib.check(self._lib.stt_engine_set_weight(
+                    self._h, name.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), arr.size))
+            _lib.check(self._lib.stt_engine_finalize(self._h))
+        self._batch = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.stt_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def encode(self, mel, return_output=False):
+        """mel: [B, frames <= 3000, n_mels] float32 (numpy or tensor).  Keeps the encoder state in
+        the engine; optionally returns the encoder output [B, 1500, d] (float32 CUDA tensor)."""
+        if not isinstance(mel, torch.Tensor):
+            mel = torch.from_numpy(np.ascontiguousarray(np.asarray(mel, dtype=np.float32)))
+        mel = mel.to(device=self.device, dtype=torch.float32).contiguous()
+        if mel.dim() == 2:
+            mel = mel[None]
+        b, frames, m = mel.shape
+        if m != self.dims["n_mels"]:
+            raise ValueError("expected %d mel channels, got %d" % (self.dims["n_mels"], m))
+        if frames > 3000:
+            mel = mel[:, :3000].contiguous()
+            frames = 3000
+        out = None
+        with torch.cuda.device(self.device):
+            if return_output:
+                out = torch.empty((b, 1500, self.dims["n_audio_state"]), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.stt_encode(self._h, mel.data_ptr(), b, frames,
+                                            out.data_ptr() if out is not None else None, self._stream()))
+        self._batch = b
+        return out
+
+    def decoder_logits(self, tokens):
+        """Teacher-forced logits [B, S, V] for tokens [B, S] over the last encoded batch."""
+        tokens = np.ascontiguousarray(np.asarray(tokens, dtype=np.int32))
+        if tokens.ndim == 1:
+            tokens = tokens[None]
+        b, s = tokens.shape
+        with torch.cuda.device(self.device):
+            out = torch.empty((b, s, self.dims["n_vocab"]), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.stt_decoder_forward(
+                self._h, tokens.ctypes.data_as(C.POINTER(C.c_int32)), b, s, out.data_ptr(), self._stream()))
+        return out
+
+    def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
+                 eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
+                 length_power=None, logits_filter=None, check_every=8):
+        prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
+        if prompt.ndim == 1:
+            prompt = prompt[None]
+        b, s = prompt.shape
+        beam = method in ("beam", "beam_search")
+        if not beam and method != "greedy":
+            raise ValueError("unsupported inference method: {}".format(method))
+        nsent = int(num_sentences) if beam else 1
+        p = GenerateParams()
+        p.method = 1 if beam else 0
+        p.num_beams = int(num_beams) if beam else 1
+        p.num_sentences = nsent
+        p.max_steps = int(max_new_tokens)
+        p.eos_token, p.pad_token = int(eos_token), int(pad_token)
+        p.early_stopping = 1 if early_stopping else 0
+        p.temperature = float(temperature) if temperature else 0.0
+        p.has_length_temperature = 0 if length_temperature is None else 1
+        p.length_temperature = float(length_temperature or 0.0)
+        p.has_length_power = 0 if length_power is None else 1
+        p.length_power = float(length_power or 0.0)
+        p.check_every = int(check_every)
+        keep = []
+        if isinstance(logits_filter, TimestampFilter):
+            a, bb = logits_filter.remove_tokens, logits_filter.remove_tokens_with_space
+            keep += [a, bb]
+            p.timestamp_filter = 1
+            p.suppress, p.n_suppress = a.ctypes.data_as(C.POINTER(C.c_int32)), a.size
+            p.suppress_first, p.n_suppress_first = bb.ctypes.data_as(C.POINTER(C.c_int32)), bb.size
+            p.timestamp_begin = logits_filter.timestamp_begin_idx
+            p.max_initial_timestamp = logits_filter.max_initial_timestamp
+            p.eos_token = int(eos_token)
+        elif logits_filter is not None:
+            if callable(logits_filter):
+                raise ValueError("a Python callable cannot run inside the device loop: pass a "
+                                 "TimestampFilter or a list of token ids")
+            a = np.ascontiguousarray(np.asarray(logits_filter, dtype=np.int32).reshape(-1))
+            keep.append(a)
+            p.suppress, p.n_suppress = a.ctypes.data_as(C.POINTER(C.c_int32)), a.size
+        tokens = np.empty((b, nsent, p.max_steps), dtype=np.int32)
+        lengths = np.empty((b, nsent), dtype=np.int32)
+        scores = np.empty((b, nsent), dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.stt_generate(
+                self._h, C.byref(p), prompt.ctypes.data_as(C.POINTER(C.c_int32)), b, s,
+                tokens.ctypes.data_as(C.POINTER(C.c_int32)), lengths.ctypes.data_as(C.POINTER(C.c_int32)),
+                scores.ctypes.data_as(C.POINTER(C.c_float)), self._stream()))
+        if not beam:
+            return tokens[:, 0], lengths[:, 0], scores[:, 0]
+        return tokens, lengths, scores
+
+
+_declared = False
+
+
+def _declare(lib):
+    global _declared
+    if _declared:
+        return
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.stt_engine_create.restype = i32
+    lib.stt_engine_create.argtypes = [C.POINTER(ModelConfig), i32, i32, i32, i32, C.POINTER(vp)]
+    lib.stt_engine_destroy.restype = None
+    lib.stt_engine_destroy.argtypes = [vp]
+    lib.stt_engine_set_weight.restype = i32
+    lib.stt_engine_set_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), i64]
+    lib.stt_engine_finalize.restype = i32
+    lib.stt_engine_finalize.argtypes = [vp]
+    lib.stt_encode.restype = i32
+    lib.stt_encode.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.stt_decoder_forward.restype = i32
+    lib.stt_decoder_forward.argtypes = [vp, C.POINTER(C.c_int32), i32, i32, vp, vp]
+    lib.stt_generate.restype = i32
+    lib.stt_generate.argtypes = [vp, C.POINTER(GenerateParams), C.POINTER(C.c_int32), i32, i32,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float), vp]
+    _declared = True
+
+
+ENGINE_SYMBOLS = ("stt_engine_create", "stt_engine_destroy", "stt_engine_set_weight",
+                  "stt_engine_finalize", "stt_encode", "stt_decoder_forward", "stt_generate")

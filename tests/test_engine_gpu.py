@@ -1,0 +1,186 @@
+"""The HIP encoder / decoder / generation path against the torch float32 oracle run on the
+same bf16-rounded weights (seeded synthetic weights: the reference ships none)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _dims_dict(d):
+    return {k: getattr(d, k) for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head",
+                                        "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
+                                        "n_text_head", "n_text_layer")}
+
+
+def _bf16_round(w):
+    return {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+
+
+@pytest.fixture(scope="module")
+def small():
+    from speech_to_text_amd.engine import WhisperEngine
+    dims = om.Dims(n_mels=80, n_audio_ctx=1500, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
+                   n_vocab=1000, n_text_ctx=64, n_text_state=128, n_text_head=2, n_text_layer=2)
+    w = _bf16_round(om.random_weights(dims, seed=0))
+    engine = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=4, max_text_len=48, max_prompt_len=8)
+    oracle = om.Whisper(dims, w)
+    g = torch.Generator().manual_seed(1)
+    mel = (torch.rand(3, 3000, 80, generator=g) * 2 - 1)
+    return dims, engine, oracle, mel
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_encoder_states(small):
+    dims, engine, oracle, mel = small
+    got = engine.encode(mel, return_output=True).cpu().numpy()
+    with torch.no_grad():
+        ref = oracle.encoder(mel).numpy()
+    assert got.shape == ref.shape == (3, 1500, 128)
+    # stated bf16 tolerance: relative L2 <= 1e-2 and max abs <= 0.05 * std(ref)
+    assert _rel_l2(got, ref) < 1e-2
+    assert np.abs(got - ref).max() < 0.05 * ref.std() * 4
+
+
+def test_short_window_is_zero_padded(small):
+    dims, engine, oracle, mel = small
+    short = mel[:1, :1234]
+    got = engine.encode(short, return_output=True).cpu().numpy()
+    padded = torch.zeros(1, 3000, 80)
+    padded[:, :1234] = short
+    with torch.no_grad():
+        ref = oracle.encoder(padded).numpy()
+    assert _rel_l2(got, ref) < 1e-2
+
+
+def test_decoder_logits_teacher_forced(small):
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    tokens = np.random.default_rng(0).integers(0, 1000, size=(3, 7)).astype(np.int32)
+    got = engine.decoder_logits(tokens).cpu().numpy()
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        ref, _ = oracle.decoder(torch.from_numpy(tokens).long(), oracle.cross_kv(enc))
+    ref = ref.numpy()
+    assert got.shape == ref.shape
+    assert _rel_l2(got, ref) < 2e-2
+
+
+def _check_tokens_against_oracle(oracle, enc, prompt, tokens, eos, pad, margin=0.05, logits_filter=None):
+    """Teacher-force the oracle on the GPU's tokens: at every step the GPU token must be the
+    oracle's argmax, or lose to it by less than `margin` in log-probability (bf16 near-tie)."""
+    b, steps = tokens.shape
+    cross = oracle.cross_kv(enc)
+    cache, offset, inputs = None, 0, torch.from_numpy(prompt).long()
+    lengths = torch.full((b,), prompt.shape[1])
+    finished = torch.zeros(b, dtype=torch.bool)
+    gen = torch.from_numpy(tokens).long()
+    exact = total = 0
+    for t in range(steps):
+        logits, cache = oracle.decoder(inputs, cross, cache, offset)
+        offset += inputs.shape[1]
+        lp = om.process_logits(logits[:, -1], lengths, gen, t, logits_filter=logits_filter)
+        for i in range(b):
+            if finished[i]:
+                assert tokens[i, t] == pad
+                continue
+            total += 1
+            best = int(lp[i].argmax())
+            if best == tokens[i, t]:
+                exact += 1
+            else:
+                assert float(lp[i, best] - lp[i, tokens[i, t]]) < margin, (i, t, best, tokens[i, t])
+        tok = gen[:, t]
+        finished = finished | (tok == eos)
+        lengths = lengths + (~finished).long()
+        inputs = tok[:, None]
+    return exact, total
+
+
+def test_greedy_tokens(small):
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    tokens, lengths, scores = engine.generate(prompt, max_new_tokens=20, eos_token=999, pad_token=999,
+                                              early_stopping=False)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        ref = om.greedy(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), max_new_tokens=20,
+                        eos=999, pad=999, early_stopping=False)
+        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 999, 999)
+    assert tokens.shape == (3, 20)
+    assert exact >= total - 2
+    same = (tokens == ref["tokens"].numpy()).all(axis=1)
+    for i in np.where(same)[0]:
+        assert abs(scores[i] - float(ref["scores"][i])) < 0.05 * 20
+        assert lengths[i] == int(ref["lengths"][i])
+
+
+def test_greedy_eos_and_suppress_list(small):
+    dims, engine, oracle, mel = small
+    engine.encode(mel[:2])
+    prompt = np.array([[5, 6], [5, 6]], dtype=np.int32)
+    free, _, _ = engine.generate(prompt, max_new_tokens=8, eos_token=999, pad_token=999, early_stopping=False)
+    eos = int(free[0, 3])                       # make the 4th token of row 0 the EOS
+    tokens, lengths, scores = engine.generate(prompt, max_new_tokens=8, eos_token=eos, pad_token=0)
+    first = int(np.argmax(free[0] == eos))
+    assert lengths[0] == first and (tokens[0, first + 1:] == 0).all() and tokens[0, first] == eos
+    banned = [int(free[1, 0])]
+    t2, _, _ = engine.generate(prompt, max_new_tokens=4, eos_token=999, pad_token=999,
+                               early_stopping=False, logits_filter=banned)
+    assert banned[0] not in t2[1].tolist()
+
+
+def test_beam_search(small):
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    tokens, lengths, scores = engine.generate(prompt, method="beam", num_beams=4, num_sentences=2,
+                                              max_new_tokens=10, eos_token=999, pad_token=999,
+                                              early_stopping=False)
+    assert tokens.shape == (3, 2, 10)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        ref = om.beam_search(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), num_beams=4,
+                             num_sentences=2, max_new_tokens=10, eos=999, pad=999, early_stopping=False)
+        g = om.greedy(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), max_new_tokens=10,
+                      eos=999, pad=999, early_stopping=False)
+    assert (scores[:, 0] >= scores[:, 1] - 1e-4).all()
+    assert (scores[:, 0] >= g["scores"].numpy() - 0.2).all()
+    # the score of each returned sequence equals the oracle's teacher-forced log-probability
+    with torch.no_grad():
+        for b in range(3):
+            seq = torch.from_numpy(tokens[b, 0]).long()[None]
+            full = torch.cat([torch.from_numpy(prompt[b:b + 1]).long(), seq], dim=1)
+            logits, _ = oracle.decoder(full[:, :-1], oracle.cross_kv(enc[b:b + 1]))
+            lp = torch.log_softmax(logits[0, 2:], dim=-1)
+            want = float(lp.gather(1, seq[0][:, None]).sum())
+            assert abs(want - scores[b, 0]) < 0.3
+    agree = (tokens[:, 0] == ref["tokens"][:, 0].numpy()).all(axis=1).sum()
+    assert agree >= 2
+
+
+def test_timestamp_filter(small):
+    from speech_to_text_amd.engine import TimestampFilter
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    filt = TimestampFilter(remove_tokens=[10, 11, 12], remove_tokens_with_space=[10, 11, 12, 13, 900],
+                           timestamp_begin_idx=920, eos_token_idx=900)
+    tokens, lengths, _ = engine.generate(prompt, max_new_tokens=12, eos_token=900, pad_token=900,
+                                         early_stopping=False, logits_filter=filt)
+    assert (tokens[:, 0] == 920).all()
+    cfg = om.FilterConfig(remove_tokens=(10, 11, 12), remove_tokens_first=(10, 11, 12, 13, 900),
+                          timestamp_begin=920, eos=900)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 900, 900, logits_filter=cfg)
+    assert exact >= total - 2
+    for row in tokens:
+        ts = row >= 920
+        assert not (ts[:-2] & ts[1:-1] & ts[2:]).any()      # never three timestamps in a row
