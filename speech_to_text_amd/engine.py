@@ -64,7 +64,7 @@ class WhisperEngine(object):
         self._lib = _lib.load()
         _declare(self._lib)
         self.dims = {k: int(dims[k]) for k in DIM_KEYS}
-        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.max_batch, self.max_beams = int(max_batch), int(max_beams)
         self.max_text_len, self.max_prompt_len = int(max_text_len), int(max_prompt_len)
         cfg = ModelConfig(gelu_tanh=1 if gelu_tanh else 0, **self.dims)
