@@ -1,5 +1,5 @@
 import numpy as np, torch, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_to_text_amd.audio.stft import WhisperSTFT
 hours = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 n = int(57_600_000 * hours)

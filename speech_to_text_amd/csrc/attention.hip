@@ -230,8 +230,8 @@ void launch_attn_decoder_self(const SelfAttnArgs& a, hipStream_t stream) {
 // for all the sequences of that window (its beams), in 1 KiB wave accesses (8 keys x 128 B).
 // Lane = (key group l >> 3, 16-byte piece l & 7).  Queries are handled CQ at a time.
 // ---------------------------------------------------------------------------------------------
-#define CQ 8
 #define CROSS_MAX_T 1536
+template <int CQ>
 __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttnArgs a) {
   __shared__ float sc[CQ][CROSS_MAX_T];
   __shared__ float qs[CQ][64];
@@ -327,5 +327,12 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
 }
 
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(attn_decoder_cross_kernel, dim3(a.heads, a.n_win), dim3(256), 0, stream, a);
+  const int nq = a.seq_per_win * a.s_new;
+  const dim3 grid(a.heads, a.n_win);
+  if (nq == 1) hipLaunchKernelGGL(attn_decoder_cross_kernel<1>, grid, dim3(256), 0, stream, a);
+  else if (nq == 2) hipLaunchKernelGGL(attn_decoder_cross_kernel<2>, grid, dim3(256), 0, stream, a);
+  else if (nq <= 4) hipLaunchKernelGGL(attn_decoder_cross_kernel<4>, grid, dim3(256), 0, stream, a);
+  else if (nq <= 6 || (nq > 8 && nq % 8 != 0 && nq % 6 == 0))
+    hipLaunchKernelGGL(attn_decoder_cross_kernel<6>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(attn_decoder_cross_kernel<8>, grid, dim3(256), 0, stream, a);
 }

@@ -84,10 +84,88 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
   }
 }
 
+// Same computation with one 256-thread block per row: decode steps have few rows, and a row's
+// pending partial sums (up to tens of KB) are then read by 256 lanes instead of 64.
+__global__ __launch_bounds__(256) void add_layernorm_row_kernel(
+    float* __restrict__ x, const float* __restrict__ slabs, int n_slabs, long slab_stride,
+    const float* __restrict__ add_bias, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
+    int m, int d, float eps, int row_mul, int row_off) {
+  __shared__ float sh[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int nv = d >> 2;
+  const long in_row = (long)row * row_mul + row_off;
+  float* xr = x + in_row * d;
+  float4 v[2];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      float4 t = ((const float4*)xr)[c];
+      if (n_slabs > 0) {
+        for (int s = 0; s < n_slabs; ++s) {
+          const float4 p = ((const float4*)(slabs + s * slab_stride + in_row * d))[c];
+          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        if (add_bias) {
+          const float4 b = ((const float4*)add_bias)[c];
+          t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        }
+        ((float4*)xr)[c] = t;
+      }
+      v[i] = t;
+      sum += t.x + t.y + t.z + t.w;
+    }
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) sh[tid >> 6] = sum;
+  __syncthreads();
+  const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+      sq += a * a + b * b + cc * cc + e * e;
+    }
+  }
+  sq = wave_sum(sq);
+  if ((tid & 63) == 0) sh[4 + (tid >> 6)] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf((sh[4] + sh[5] + sh[6] + sh[7]) / d + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (out_bf16) {
+        uint2 p;
+        p.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+        p.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+        ((uint2*)(out_bf16 + (long)row * d))[c] = p;
+      }
+      if (out_f32) ((float4*)(out_f32 + (long)row * d))[c] = o;
+    }
+  }
+}
+
 void launch_add_layernorm(float* x, const float* slabs, int n_slabs, long slab_stride,
                           const float* add_bias, const float* gamma, const float* beta,
                           bf16_t* out_bf16, float* out_f32, int m, int d, float eps,
                           int row_mul, int row_off, hipStream_t stream) {
+  if (m <= 1024) {     // d <= 2048 = 256 lanes x 2 float4
+    hipLaunchKernelGGL(add_layernorm_row_kernel, dim3(m), dim3(256), 0, stream, x, slabs, n_slabs,
+                       slab_stride, add_bias, gamma, beta, out_bf16, out_f32, m, d, eps, row_mul,
+                       row_off);
+    return;
+  }
   hipLaunchKernelGGL(add_layernorm_kernel, dim3((m + 3) / 4), dim3(256), 0, stream, x, slabs,
                      n_slabs, slab_stride, add_bias, gamma, beta, out_bf16, out_f32, m, d, eps,
                      row_mul, row_off);

@@ -309,7 +309,7 @@ int stt_engine_finalize(stt_engine* e) {
   if ((rc = dev_alloc(e, &e->dx, MR * d)) || (rc = dev_alloc(e, &e->dh, MR * d)) ||
       (rc = dev_alloc(e, &e->dqkv, MR * 3 * d)) || (rc = dev_alloc(e, &e->datt, MR * d)) ||
       (rc = dev_alloc(e, &e->dq, MR * d)) || (rc = dev_alloc(e, &e->df, MR * 4 * d)) ||
-      (rc = dev_alloc(e, &e->slabs, (size_t)80 * slab_rows * d)) ||
+      (rc = dev_alloc(e, &e->slabs, (size_t)8 * slab_rows * d)) ||
       (rc = dev_alloc(e, &e->tokens_in, MR)) || (rc = dev_alloc(e, &e->positions, MR))) return rc;
   e->self_k.resize(c.n_text_layer); e->self_v.resize(c.n_text_layer);
   for (int l = 0; l < c.n_text_layer; ++l)

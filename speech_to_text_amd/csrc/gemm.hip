@@ -171,19 +171,22 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Small-M kernel (decode): every wave owns 16 output features and streams their weight rows
-// straight from HBM into registers, 128 contiguous bytes per row per step (lane group g reads
-// the 16-byte pieces 2g and 2g+1; the activation fragment uses the same k order).  Activations
-// (M x K, a few hundred KB at most) come from L2.  blockIdx.y selects a K slice (split-K).
+// Small-M kernel (decode): a block owns 16 output features; its 4 waves take interleaved
+// 64-wide K steps, so that per iteration the block reads 512 contiguous bytes of each of the 16
+// weight rows straight from HBM into registers (lane group g reads the 16-byte pieces 2g and
+// 2g+1 of its wave's 128 bytes; the activation fragment uses the same k order).  Activations
+// (M x K, a few hundred KB at most) come from L2.  The four partial tiles are summed through
+// LDS and the epilogue is applied once.  blockIdx.y selects a K slice (split-K across blocks,
+// raw partial sums to slabs).
 // ---------------------------------------------------------------------------------------------
 template <int MT, int EPI>   // MT = ceil(M / 16)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int k_per_split,
                                                           float* __restrict__ slabs) {
+  __shared__ f4_t part[3][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  const int n0 = blockIdx.x * 16;
   const int M = g.m, N = g.n, K = g.k;
-  if (n0 >= N) return;
   int wn = n0 + fr; wn = wn < N ? wn : N - 1;
   const int kbeg = blockIdx.y * k_per_split;
   const bf16_t* __restrict__ wrow = g.w + (long)wn * K + kbeg + 16 * fg;
@@ -197,10 +200,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f4_t{0.f, 0.f, 0.f, 0.f};
 
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
   const int nsteps = k_per_split / 64;
-#pragma unroll 2
-  for (int s = 0; s < nsteps; ++s) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+#pragma unroll 4
+  for (int s = wave; s < nsteps; s += 4) {
     const u4_t w0 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64));
     const u4_t w1 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64 + 8));
     const bf8_t wf0 = __builtin_bit_cast(bf8_t, w0), wf1 = __builtin_bit_cast(bf8_t, w1);
@@ -212,6 +215,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, a1, acc[t], 0, 0, 0);
     }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) part[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] += part[0][t][lane] + part[1][t][lane] + part[2][t][lane];
 
   const int n = n0 + 4 * fg;
   if (n >= N) return;
@@ -223,7 +234,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
     float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
     if (slabs) {
       float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
-      for (int r = 0; r < nv; ++r) o[r] = v[r];
+      if (nv == 4) *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+      else for (int r = 0; r < nv; ++r) o[r] = v[r];
       continue;
     }
     if (g.bias) for (int r = 0; r < nv; ++r) v[r] += g.bias[n + r];
@@ -246,13 +258,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
   }
 }
 
+// Split K across blocks only when there are too few 16-feature blocks to cover the chip, and
+// never into more than 8 slices (the consumer re-reads every slice).
 int pick_split_k(int m, int n, int k, int n_cu) {
-  const int col_blocks = (n + 63) / 64;
+  const int col_blocks = (n + 15) / 16;
   const int steps = k / 64;
   int best = 1;
-  for (int s = 1; s <= steps; ++s) {
+  for (int s = 1; s <= 8 && s <= steps; ++s) {
     if (steps % s) continue;
-    if (steps / s < 2) break;              // at least 128 of K per block
+    if (steps / s < 8) break;              // at least two steps per wave
     best = s;
     if ((long)col_blocks * s >= 2L * n_cu) break;
   }
@@ -263,7 +277,7 @@ int pick_split_k(int m, int n, int k, int n_cu) {
 template <int MT>
 static void launch_skinny_mt(const GemmArgs& g, int epilogue, int split_k, float* slabs,
                              hipStream_t stream) {
-  dim3 grid((g.n + 63) / 64, split_k, 1);
+  dim3 grid((g.n + 15) / 16, split_k, 1);
   const int kps = g.k / split_k;
   float* sl = split_k > 1 || epilogue < 0 ? slabs : nullptr;
   if (sl) {
