@@ -175,4 +175,33 @@ class WhisperSTFT(MelSTFT):
         return mel
 
 
+    # -- a clip computed in pieces (one per GPU): frames [frame_begin, +frame_count) ------------
+    def piece_spectrogram(self, pcm_piece, sample_origin, n_total, frame_begin, frame_count):
+        """First half of the log-mel for one piece of a clip: returns (z, piece_max, state) where
+        z = (log10(mel) + 4) / 4 for the piece's frames, piece_max is a 1-element CUDA tensor with
+        the piece's maximum of log10(mel), and state must be handed to `finish_piece` together
+        with the clip-wide maximum (the max over every piece's piece_max)."""
+        pcm = self._as_device_audio(pcm_piece)
+        with torch.cuda.device(pcm.device):
+            ws_bytes = self._lib.stt_logmel_workspace_bytes(max(int(frame_count), 3) * 160)
+            mel = torch.empty((int(frame_count), self.n_mel_channels), dtype=torch.float32, device=pcm.device)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=pcm.device)
+            piece_max = torch.empty((1,), dtype=torch.float32, device=pcm.device)
+            stream = torch.cuda.current_stream(pcm.device).cuda_stream
+            _lib.check(self._lib.stt_logmel_stage1(
+                self._plan(pcm.device), pcm.data_ptr(), int(sample_origin), pcm.numel(), int(n_total),
+                int(frame_begin), int(frame_count), mel.data_ptr(), piece_max.data_ptr(), ws.data_ptr(),
+                ws_bytes, stream))
+        return mel, piece_max, ws
+
+    def finish_piece(self, mel, clip_max, state):
+        with torch.cuda.device(mel.device):
+            clip_max = clip_max.to(device=mel.device, dtype=torch.float32).contiguous()
+            stream = torch.cuda.current_stream(mel.device).cuda_stream
+            _lib.check(self._lib.stt_logmel_stage2(
+                self._plan(mel.device), mel.data_ptr(), mel.shape[0], clip_max.data_ptr(),
+                state.data_ptr(), stream))
+        return mel
+
+
 _mel_classes = {'MelSTFT': MelSTFT, 'WhisperSTFT': WhisperSTFT}

@@ -1,0 +1,173 @@
+"""``Runtime`` implementation that runs Whisper on the MI355X engine.
+
+It satisfies what ``models/stt/whisper.py`` asks of ``self.model`` when a runtime is plugged in
+through ``BaseModel(runtime = ...)`` (models/interfaces/base_model.py:179-189, 365-374):
+
+* ``__call__(mel, tokens = ..., tokens_length = ..., max_length = ... | max_new_tokens = ...,
+  method = ..., num_beams = ..., ...)`` returning an object with ``tokens`` / ``lengths`` /
+  ``scores`` that ``process_model_output`` accepts (whisper.py:247-251);
+* ``set_tokens`` (models/stt/base_stt.py:68), ``is_enc_dec`` and a non-None ``decoder``
+  (models/interfaces/base_text_model.py:45-48);
+* ``encoder(mel)`` / ``decoder(tokens, encoder_output = ...)`` for language detection
+  (whisper.py:174-186).
+
+``path`` is a directory or file holding the weights: ``*.safetensors`` / ``*.pt`` / ``*.npz`` with
+OpenAI or Hugging Face Whisper names, or the string ``random:<size>[:seed]`` for seeded
+synthetic weights (no checkpoint can be downloaded offline).
+"""
+import collections
+import os
+
+import numpy as np
+import torch
+
+from .runtime import Runtime
+from ..engine import WhisperEngine, TimestampFilter, whisper_dims
+from .. import weights as W
+
+InferenceOutput = collections.namedtuple(
+    "InferenceOutput", ["tokens", "lengths", "scores", "logits", "state", "attention_weights"]
+)
+
+
+def _load_state_dict(path):
+    if os.path.isdir(path):
+        for name in sorted(os.listdir(path)):
+            if name.endswith(('.safetensors', '.pt', '.pth', '.npz')):
+                return _load_state_dict(os.path.join(path, name))
+        raise FileNotFoundError('no weight file (*.safetensors, *.pt, *.npz) in {}'.format(path))
+    if path.endswith('.safetensors'):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    elif path.endswith('.npz'):
+        with np.load(path, allow_pickle=False) as f:
+            sd = {k: torch.from_numpy(f[k]) for k in f.files}
+    else:
+        sd = torch.load(path, map_location='cpu', weights_only=True)
+        if 'model_state_dict' in sd:
+            sd = sd['model_state_dict']
+    if any(k.startswith('model.encoder.') for k in sd):
+        return W.from_hf_state_dict(sd)
+    return W.from_openai_state_dict(sd)
+
+
+class _Engine(object):
+    """What ``load_engine`` caches per path: dims + weights; device engines are built lazily for
+    the capacity a call needs."""
+
+    def __init__(self, dims, weights, gelu_tanh=True):
+        self.dims, self.weights, self.gelu_tanh = dims, weights, gelu_tanh
+        self._built = None
+        self._cap = None
+
+    def get(self, batch, beams, text_len, prompt_len):
+        cap = self._cap
+        if cap is None or batch > cap[0] or beams > cap[1] or text_len > cap[2] or prompt_len > cap[3]:
+            new = (max(batch, cap[0] if cap else 1), max(beams, cap[1] if cap else 1),
+                   max(text_len, cap[2] if cap else 2), max(prompt_len, cap[3] if cap else 1))
+            self._built = None
+            self._built = WhisperEngine(self.dims, self.weights, max_batch=new[0], max_beams=new[1],
+                                        max_text_len=new[2], max_prompt_len=new[3],
+                                        gelu_tanh=self.gelu_tanh)
+            self._cap = new
+        return self._built
+
+
+class MI355XRuntime(Runtime):
+    _engines = {}
+
+    def __init__(self, path, *, max_batch=1, **kwargs):
+        super().__init__(path, **kwargs)
+        self.is_enc_dec = True
+        self.sos_token = -1
+        self.eos_token = -1
+        self.pad_token = -1
+        self._max_batch = max_batch
+
+    # -- Runtime interface -------------------------------------------------
+    @staticmethod
+    def load_engine(path, *, gelu='tanh', **kwargs):
+        if isinstance(path, str) and path.startswith('random:'):
+            parts = path.split(':')
+            dims = whisper_dims(parts[1])
+            seed = int(parts[2]) if len(parts) > 2 else 0
+            weights = W.random_whisper_weights(dims, seed)
+        else:
+            weights = _load_state_dict(path)
+            dims = W.dims_from_openai_state_dict(weights)
+        return _Engine(dims, weights, gelu_tanh=(gelu == 'tanh'))
+
+    def set_tokens(self, sos_token=None, eos_token=None, pad_token=None):
+        if sos_token not in (-1, None): self.sos_token = sos_token
+        if eos_token not in (-1, None): self.eos_token = eos_token
+        if pad_token not in (-1, None): self.pad_token = pad_token
+
+    @property
+    def dims(self):
+        return self.engine.dims
+
+    @property
+    def vocab_size(self):
+        return self.engine.dims['n_vocab']
+
+    def __call__(self, inputs, *, tokens=None, tokens_length=None, encoder_output_lengths=None,
+                 max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
+                 num_sentences=1, temperature=None, length_temperature=None, length_power=None,
+                 logits_filter=None, early_stopping=True, **_ignored):
+        """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
+        arguments (lang, verbose, ...) are ignored, as the reference's runtimes do."""
+        if isinstance(inputs, torch.Tensor):
+            mel = inputs
+        else:
+            mel = torch.from_numpy(np.ascontiguousarray(np.asarray(inputs, dtype=np.float32)))
+        if mel.dim() == 2:
+            mel = mel[None]
+        b = mel.shape[0]
+        if tokens is None:
+            if self.sos_token in (-1, None):
+                raise ValueError('no prompt given and no sos token set')
+            tokens = np.full((b, 1), self.sos_token, dtype=np.int32)
+        tokens = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens, dtype=np.int32)
+        if tokens.ndim == 1:
+            tokens = np.tile(tokens[None], [b, 1])
+        s = int(tokens_length) if tokens_length is not None else tokens.shape[1]
+        tokens = np.ascontiguousarray(tokens[:, :s])
+        if self.eos_token in (-1, None):
+            raise ValueError('call set_tokens(eos_token = ..., pad_token = ...) first')
+        # generation_utils.py:794-801
+        if max_length is None:
+            max_length = s + (256 if max_new_tokens is None else int(max_new_tokens))
+        max_steps = int(max_length) - s
+        if max_steps < 1:
+            raise ValueError('prompt of {} tokens leaves no room under max_length = {}'.format(s, max_length))
+        beam = method in ('beam', 'beam_search')
+        eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s)
+        pad = self.pad_token if self.pad_token not in (-1, None) else self.eos_token
+        eng.encode(mel)
+        toks, lengths, scores = eng.generate(
+            tokens, method=method, num_beams=num_beams, num_sentences=num_sentences,
+            max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
+            early_stopping=early_stopping, temperature=temperature,
+            length_temperature=length_temperature, length_power=length_power,
+            logits_filter=logits_filter)
+        return InferenceOutput(tokens=toks, lengths=lengths, scores=scores, logits=None, state=None,
+                               attention_weights=None)
+
+    # -- callables used by detect_language --------------------------------
+    def encoder(self, mel, training=False, **_):
+        if not isinstance(mel, torch.Tensor):
+            mel = torch.from_numpy(np.ascontiguousarray(np.asarray(mel, dtype=np.float32)))
+        if mel.dim() == 2:
+            mel = mel[None]
+        eng = self.engine.get(max(mel.shape[0], self._max_batch), 1, 8, 4)
+        return eng.encode(mel, return_output=True)
+
+    def decoder(self, tokens, encoder_output=None, training=False, **_):
+        """Logits [B, S, V] of a teacher-forced pass over the windows last given to ``encoder``
+        (``encoder_output`` is accepted for signature parity; the engine keeps its own copy)."""
+        tokens = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens, dtype=np.int32)
+        if tokens.ndim == 1:
+            tokens = tokens[None]
+        eng = self.engine.get(max(tokens.shape[0], self._max_batch), 1, max(8, tokens.shape[1] + 1),
+                              max(4, tokens.shape[1]))
+        return eng.decoder_logits(tokens)

@@ -1,0 +1,354 @@
+"""``Whisper`` speech-to-text wrapper over the MI355X runtime, with the method names, arguments
+and result dictionaries of the reference's ``models/stt/whisper.py`` / ``base_stt.py``:
+``predict`` / ``infer`` / ``_infer_segments`` / ``detect_language`` / ``get_inference_tokens``
+plus ``search`` (README "Search and partial alignment").
+
+Host code (Python) like the reference's wrapper; everything numeric runs in the runtime.
+"""
+import numpy as np
+import torch
+
+from ..audio.audio_processing import WHISPER_TRIM_KWARGS, read_audio
+from ..audio.stft import WhisperSTFT
+from ..engine import TimestampFilter
+from ..runtimes import build_runtime
+from ..text.metrics import edit_distance, process_model_output
+
+# language codes in the order of the tokenizer's language tokens (whisper.py:418-518)
+LANGUAGES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta "
+             "no th ur hr bg lt la mi ml cy sk te fa lv bn sr az sl kn et mk br eu is hy ne mn bs kk "
+             "sq sw gl mr pa si km sn yo so af oc ka be tg sd gu am yi lo uz fo ht ps tk nn mt sa lb "
+             "my bo tl mg as tt haw ln ha ba jw su").split()
+
+
+class WhisperVocabulary(object):
+    """Special-token ids of the `openai/whisper-base` tokenizer the reference always loads
+    (utils/text/tokenizer.py:870-872): 50364 entries, timestamps start right after.  An optional
+    `tokenizers.Tokenizer` (from a local tokenizer.json) provides text decoding and the
+    non-speech token list; without it token ids are returned as text."""
+
+    def __init__(self, tokenizer=None, vocab_size=50364):
+        self.tokenizer = tokenizer
+        self.vocab_size = vocab_size
+        self.eos_token_idx = 50257
+        self.sos_token_idx = 50258
+        self.lang_to_idx = {l: 50259 + i for i, l in enumerate(LANGUAGES)}
+        self.idx_to_lang = {i: l for l, i in self.lang_to_idx.items()}
+        self.translate_token_idx = 50358
+        self.transcribe_token_idx = 50359
+        self.start_of_lm_idx = 50360
+        self.start_of_prev_token_idx = 50361
+        self.nospeech_token_idx = 50362
+        self.notimestamps_idx = 50363
+        self.timestamp_begin_idx = vocab_size
+
+    @classmethod
+    def from_file(cls, tokenizer_json):
+        from tokenizers import Tokenizer
+        return cls(Tokenizer.from_file(tokenizer_json))
+
+    def token_id(self, text):
+        if self.tokenizer is None:
+            return None
+        ids = self.tokenizer.encode(text, add_special_tokens=False).ids
+        return ids[0] if len(ids) == 1 else ids
+
+    @property
+    def special_token_indexes(self):
+        return [self.sos_token_idx, self.start_of_lm_idx, self.start_of_prev_token_idx,
+                self.nospeech_token_idx, self.notimestamps_idx]
+
+    @property
+    def non_speech_token_indexes(self):
+        """OpenAI's non-speech symbol set (whisper.py:132-153); needs the tokenizer."""
+        if self.tokenizer is None:
+            return ()
+        symbols = list("\"#()*+/:;<=>@[\\]^_`{|}~「」『』")
+        symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+        misc = set("♩♪♫♬♭♮♯")
+        result = set()
+        for t in (" -", " '"):
+            i = self.token_id(t)
+            if isinstance(i, int): result.add(i)
+        for symbol in symbols + list(misc):
+            for toks in (self.token_id(symbol), self.token_id(" " + symbol)):
+                if isinstance(toks, int):
+                    result.add(toks)
+                elif symbol in misc and toks:
+                    result.add(toks[0])
+        return tuple(sorted(result))
+
+    def decode(self, tokens):
+        tokens = [int(t) for t in tokens if int(t) < self.eos_token_idx]
+        if self.tokenizer is None:
+            return ' '.join(str(t) for t in tokens)
+        return self.tokenizer.decode(tokens)
+
+
+class Whisper(object):
+    """`Whisper(pretrained = 'large-v3', runtime = 'mi355x', path = ...)`."""
+
+    def __init__(self, lang='multi', pretrained='base', *, runtime='mi355x', path=None,
+                 vocabulary=None, max_batch=1, **kwargs):
+        self.lang = 'en' if pretrained and '.en' in pretrained else lang
+        self.pretrained = pretrained
+        self.rate = 16000
+        self.max_input_length = 3000
+        self.max_output_length = 256
+        self.pad_mel_value = 0.
+        self.vocabulary = vocabulary or WhisperVocabulary()
+        if path is None:
+            path = 'random:{}'.format(pretrained)
+        self.model = build_runtime(runtime, path, max_batch=max_batch,
+                                   **{k: v for k, v in kwargs.items() if k in ('gelu', 'reload')})
+        n_mels = self.model.dims['n_mels']
+        self.mel_fn = WhisperSTFT(n_mel_channels=n_mels)
+        self.trim_kwargs = dict(trim_silence=True, **WHISPER_TRIM_KWARGS)
+        self.model.set_tokens(sos_token=self.sos_token_idx, eos_token=self.eos_token_idx,
+                              pad_token=self.eos_token_idx)
+        t = list(self.vocabulary.non_speech_token_indexes) + list(self.vocabulary.special_token_indexes)
+        self.remove_tokens = np.array(t, 'int32')
+        space = self.vocabulary.token_id(' ')
+        self.remove_tokens_with_space = np.array(
+            ([space] if isinstance(space, int) else []) + [self.eos_token_idx] + t, 'int32')
+
+    # ---- token properties (whisper.py:80-131)
+    sos_token_idx = property(lambda self: self.vocabulary.sos_token_idx)
+    eos_token_idx = property(lambda self: self.vocabulary.eos_token_idx)
+    transcribe_token_idx = property(lambda self: self.vocabulary.transcribe_token_idx)
+    translate_token_idx = property(lambda self: self.vocabulary.translate_token_idx)
+    start_of_prev_token_idx = property(lambda self: self.vocabulary.start_of_prev_token_idx)
+    timestamp_begin_idx = property(lambda self: self.vocabulary.timestamp_begin_idx)
+    languages = property(lambda self: list(self.vocabulary.lang_to_idx.keys()))
+    language_indexes = property(lambda self: list(self.vocabulary.idx_to_lang.keys()))
+    is_encoder_decoder = True
+    compiled_infer = property(lambda self: self.model)       # base_model.py:365-374
+
+    @property
+    def time_precision(self):
+        return 2 * self.mel_fn.hop_length / self.rate          # 0.02 s
+
+    def _get_sample_time(self, frames):
+        return 0. if frames == 0 else frames * self.mel_fn.hop_length / self.rate
+
+    @property
+    def logits_filter(self):
+        """The reference's opt-in timestamp filter (whisper.py:354-416) as a device-side filter."""
+        return TimestampFilter(self.remove_tokens, self.remove_tokens_with_space,
+                               self.timestamp_begin_idx, self.eos_token_idx)
+
+    # ---- inputs
+    def get_audio(self, data, **kwargs):
+        _, audio = read_audio(data, rate=self.rate, **{**self.trim_kwargs, **kwargs})
+        return audio
+
+    def get_input(self, audio, pad_or_trim=True, **kwargs):
+        """Raw audio / filename -> mel [frames, n_mels] (CUDA tensor)."""
+        if isinstance(audio, dict):
+            audio = audio.get('audio', audio.get('filename'))
+        if hasattr(audio, 'shape') and len(audio.shape) >= 2 and audio.shape[-1] == self.mel_fn.n_mel_channels:
+            mel = torch.as_tensor(audio)
+        else:
+            keep = {k: v for k, v in kwargs.items() if k in ('normalize', 'trim_silence', 'mode', 'threshold',
+                                                            'min_silence', 'replace_by', 'min_voice_time')}
+            mel = self.mel_fn(self.get_audio(audio, **keep))[0]
+        return self.pad_or_trim(mel) if pad_or_trim else mel
+
+    def pad_or_trim(self, mel):
+        if mel.shape[0] > self.max_input_length:
+            return mel[: self.max_input_length]
+        if mel.shape[0] < self.max_input_length:
+            return torch.nn.functional.pad(mel, (0, 0, 0, self.max_input_length - mel.shape[0]),
+                                           value=self.pad_mel_value)
+        return mel
+
+    def get_inference_tokens(self, lang=None, task=None, **_):
+        if not lang:
+            return [self.sos_token_idx]
+        return [self.sos_token_idx, self.vocabulary.lang_to_idx[lang],
+                self.translate_token_idx if task == 'translate' else self.transcribe_token_idx]
+
+    def decode_output(self, tokens):
+        return self.vocabulary.decode(tokens)
+
+    # ---- language detection (whisper.py:174-202)
+    def detect_language(self, audio, **kwargs):
+        mel = self.get_input(audio, pad_or_trim=True)
+        if mel.dim() == 2:
+            mel = mel[None]
+        tokens = np.full((mel.shape[0], 1), self.sos_token_idx, dtype=np.int32)
+        enc = self.model.encoder(mel)
+        pred = self.model.decoder(tokens, encoder_output=enc)
+        idx = torch.as_tensor(self.language_indexes, device=pred.device)
+        probs = torch.softmax(pred[0, -1, :][idx], dim=-1).cpu().numpy()
+        return self.languages[int(np.argmax(probs))], {l: float(p) for l, p in zip(self.languages, probs)}
+
+    # ---- sequential long-form decoding (whisper.py:204-331)
+    def _infer_segments(self, mel, *, lang=None, verbose=True, force_detect_language=False,
+                        condition_on_previous_text=True, segment_processing=None, **kwargs):
+        kwargs['encoder_output_lengths'] = 1500
+        kwargs.setdefault('max_length', self.max_output_length)
+        seek = kwargs.pop('seek', 0)
+        n_frames = len(mel)
+        input_stride = 2
+        all_tokens, segments = [], []
+        while seek < n_frames:
+            segment = mel[seek: seek + self.max_input_length]
+            segment_length = len(segment)
+            segment = self.pad_or_trim(segment)
+            if lang is None and force_detect_language:
+                lang, _ = self.detect_language(segment)
+            tokens = self.get_inference_tokens(lang=lang, **kwargs)
+            if condition_on_previous_text and len(all_tokens):
+                tokens = np.array([self.start_of_prev_token_idx] +
+                                  all_tokens[-(kwargs['max_length'] // 2 - 1):] + tokens, 'int32')
+            else:
+                tokens = np.array(tokens, 'int32')
+            out = self.compiled_infer(segment[None], tokens=tokens[None], tokens_length=len(tokens), **kwargs)
+            tokens = process_model_output(out)[0] if hasattr(out, 'tokens') else out[0]
+            if len(tokens) and isinstance(tokens[0], (list, np.ndarray)):
+                tokens = tokens[0]
+            tokens = np.array(tokens, dtype=np.int32)
+            if lang is None:
+                lang = self.vocabulary.idx_to_lang.get(int(tokens[0]), None) if len(tokens) else None
+                tokens = tokens[2:]
+            timestamp_offset = self._get_sample_time(seek)
+            ts = tokens >= self.timestamp_begin_idx
+            consecutive = np.where(np.logical_and(ts[:-1], ts[1:]))[0] + 1
+            if len(consecutive) > 0:
+                last_slice = 0
+                for current_slice in consecutive:
+                    sliced = tokens[last_slice: current_slice]
+                    start_pos = sliced[0] - self.timestamp_begin_idx
+                    end_pos = sliced[-1] - self.timestamp_begin_idx
+                    sliced = sliced[1:-1]
+                    segments.append({
+                        'start': timestamp_offset + start_pos * self.time_precision,
+                        'end': timestamp_offset + end_pos * self.time_precision,
+                        'text': self.decode_output(sliced),
+                        'tokens': sliced[sliced < self.eos_token_idx], 'lang': lang})
+                    if segment_processing is not None:
+                        segment_processing(segments[-1], segment=segment)
+                    last_slice = current_slice
+                last_pos = tokens[last_slice - 1] - self.timestamp_begin_idx
+                seek += int(last_pos) * input_stride
+                all_tokens.extend(tokens[: last_slice + 1].tolist())
+            else:
+                duration = self._get_sample_time(segment_length)
+                stamps = tokens[ts]
+                if len(stamps) > 0 and stamps[-1] != self.timestamp_begin_idx:
+                    duration = float(stamps[-1] - self.timestamp_begin_idx) * self.time_precision
+                tokens = tokens[tokens < self.eos_token_idx]
+                segments.append({'start': timestamp_offset, 'end': timestamp_offset + duration,
+                                 'text': self.decode_output(tokens), 'tokens': tokens, 'lang': lang})
+                if segment_processing is not None:
+                    segment_processing(segments[-1], segment=segment)
+                seek += self.max_input_length if segment_length >= self.max_input_length else segment_length
+                all_tokens.extend(tokens.tolist())
+        for seg in segments:
+            seg['time'] = seg['end'] - seg['start']
+        return segments
+
+    # ---- independent windows, batched (and shardable across GPUs)
+    def infer_windows(self, mel, *, lang='en', task=None, batch_size=32, shard=None, **kwargs):
+        """Transcribes the 30 s windows of `mel` independently of each other (the mode the
+        reference reaches with condition_on_previous_text = False and no timestamp seek,
+        whisper.py:301-323), `batch_size` windows per engine call.  `shard = (rank, world)`
+        keeps the windows w with w % world == rank."""
+        n_frames = len(mel)
+        starts = list(range(0, n_frames, self.max_input_length))
+        mine = [w for w in range(len(starts)) if shard is None or w % shard[1] == shard[0]]
+        prompt = np.array(self.get_inference_tokens(lang=lang, task=task), 'int32')
+        kwargs.setdefault('max_length', self.max_output_length)
+        results = {}
+        for i in range(0, len(mine), batch_size):
+            ws = mine[i: i + batch_size]
+            batch = torch.stack([self.pad_or_trim(mel[starts[w]: starts[w] + self.max_input_length]) for w in ws])
+            out = self.compiled_infer(batch, tokens=np.tile(prompt[None], [len(ws), 1]),
+                                      tokens_length=len(prompt), **kwargs)
+            toks = process_model_output(out)
+            for w, t in zip(ws, toks):
+                while len(t) and isinstance(t[0], (list, np.ndarray)):
+                    t = t[0]
+                t = np.asarray(t, dtype=np.int32)
+                seg_len = min(self.max_input_length, n_frames - starts[w])
+                results[w] = {'start': self._get_sample_time(starts[w]),
+                              'end': self._get_sample_time(starts[w] + seg_len),
+                              'tokens': t[t < self.eos_token_idx], 'lang': lang,
+                              'text': self.decode_output(t)}
+        return results
+
+    def infer(self, audio, *, condition_on_previous_text=True, independent_windows=False, **kwargs):
+        infos = audio.copy() if isinstance(audio, dict) else {}
+        mel = self.get_input(audio, pad_or_trim=False, **kwargs)
+        run_kwargs = {k: v for k, v in kwargs.items() if k not in
+                      ('normalize', 'trim_silence', 'mode', 'threshold', 'min_silence', 'replace_by',
+                       'min_voice_time')}
+        if independent_windows:
+            res = self.infer_windows(mel, **run_kwargs)
+            segments = [res[w] for w in sorted(res)]
+            for seg in segments:
+                seg['time'] = seg['end'] - seg['start']
+        else:
+            segments = self._infer_segments(mel, condition_on_previous_text=condition_on_previous_text,
+                                            **run_kwargs)
+        infos.update({'text': ' '.join(seg['text'] for seg in segments), 'segments': segments})
+        if 'lang' not in infos and segments and 'lang' in segments[0]:
+            infos['lang'] = segments[0]['lang']
+        if isinstance(audio, str):
+            infos['filename'] = audio
+        return infos
+
+    def predict(self, audios, **kwargs):
+        if not isinstance(audios, (list, tuple)):
+            audios = [audios]
+        return [self.infer(a, **kwargs) for a in audios]
+
+    # ---- keyword search by partial alignment (README "Search and partial alignment")
+    def search(self, keyword, audio, threshold=0.8, **kwargs):
+        """Transcribes with timestamps and scores `keyword` against every segment's text with
+        edit_distance(partial = True); returns the segments whose similarity 1 - distance reaches
+        `threshold`, each with the character span of the best alignment."""
+        kwargs.setdefault('logits_filter', self.logits_filter)
+        result = audio if isinstance(audio, dict) and 'segments' in audio else self.infer(audio, **kwargs)
+        hits = []
+        for seg in result['segments']:
+            text = seg['text']
+            if not text:
+                continue
+            dist, matrix = edit_distance(keyword, text, partial=True, return_matrix=True, normalize=True)
+            score = 1. - dist
+            if score >= threshold:
+                end = int(np.argmin(matrix[-1, 1:])) + 1
+                hits.append({'start': seg['start'], 'end': seg['end'], 'text': text, 'score': score,
+                             'span': (max(0, end - len(keyword)), end)})
+        return {'keyword': keyword, 'matches': hits, 'text': result['text']}
+
+
+_models = {}
+
+
+def get_model(lang=None, model=None, **kwargs):
+    if isinstance(model, Whisper):
+        return model
+    key = model or 'base'
+    if key not in _models:
+        _models[key] = Whisper(pretrained=key, **kwargs)
+    return _models[key]
+
+
+def transcribe(audios, *, lang=None, model=None, **kwargs):
+    """models/stt/__init__.py:45-46."""
+    return get_model(lang=lang, model=model).predict(audios, lang=lang, **kwargs)
+
+
+def translate(audios, *, lang=None, model=None, **kwargs):
+    """models/stt/__init__.py:48-51."""
+    return get_model(lang=lang, model=model).predict(audios, lang=lang, task='translate', **kwargs)
+
+
+def search(keyword, audios, *, lang=None, model=None, **kwargs):
+    m = get_model(lang=lang, model=model)
+    if not isinstance(audios, (list, tuple)):
+        audios = [audios]
+    return [m.search(keyword, a, lang=lang, **kwargs) for a in audios]

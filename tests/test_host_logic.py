@@ -1,0 +1,100 @@
+"""Host-side logic that needs no GPU: audio pre-steps, edit distance, runtime registry,
+weight-name normalisation."""
+import os
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from oracle import frontend as oracle_frontend
+
+
+def test_audio_presteps_match_oracle(golden_dir):
+    from speech_to_text_amd.audio.audio_processing import (WHISPER_TRIM_KWARGS, normalize_audio,
+                                                           read_audio, trim_silence_rms)
+    rate, pcm = wavfile.read(os.path.join(golden_dir, "audio_test.wav"))
+    a = normalize_audio(pcm, max_val=1.)
+    assert a.dtype == np.float32 and abs(np.abs(a).max() - 1) < 1e-6
+    assert np.array_equal(a, oracle_frontend.normalize_audio(pcm))
+    t = trim_silence_rms(a, rate=rate, **WHISPER_TRIM_KWARGS)
+    assert np.array_equal(t, oracle_frontend.whisper_prepare_audio(pcm))
+    assert len(t) == 63360            # notebook cell-13: 396 frames, end = 3.96 s
+    _, via_reader = read_audio(os.path.join(golden_dir, "audio_test.wav"), trim_silence=True,
+                               **WHISPER_TRIM_KWARGS)
+    assert np.array_equal(via_reader, t)
+    for mode in ("start_end", "start", "end"):
+        x = trim_silence_rms(a, rate=rate, mode=mode)
+        y = oracle_frontend.trim_silence_rms(a, rate=rate, mode=mode)
+        assert np.array_equal(x, y)
+
+
+def test_edit_distance_readme_matrices():
+    from speech_to_text_amd.text.metrics import edit_distance
+    # README.md:85-108 of the reference
+    d, m = edit_distance("cat", "ct", return_matrix=True, normalize=False)
+    assert d == 1 and m.tolist() == [[0, 1, 2], [1, 0, 1], [2, 1, 1], [3, 2, 1]]
+    d, m = edit_distance("cat", "the ct is", partial=True, return_matrix=True, normalize=False)
+    assert d == 1
+    assert m.tolist() == [[0] * 10, [1, 1, 1, 1, 1, 0, 1, 1, 1, 1], [2, 2, 2, 2, 2, 1, 1, 2, 2, 2],
+                          [3, 2, 3, 3, 3, 2, 1, 2, 3, 3]]
+    assert abs(edit_distance("cat", "the ct is", partial=True) - 1 / 3) < 1e-12
+    assert edit_distance([1, 2, 3], [1, 2, 3]) == 0
+    assert edit_distance("abc", "abd", replacement_cost={"c": {"d": 0.5}}, normalize=False) == 0.5
+
+
+def test_runtime_registry_and_errors():
+    from speech_to_text_amd.runtimes import build_runtime, Runtime, _runtimes
+    assert "mi355x" in _runtimes and issubclass(_runtimes["mi355x"], Runtime)
+    with pytest.raises(ValueError):
+        build_runtime("trt_llm", "/nowhere")
+
+
+def test_weight_name_normalisation():
+    import torch
+    from speech_to_text_amd import weights as W
+    from speech_to_text_amd.engine import whisper_dims
+    dims = dict(whisper_dims("tiny"), n_audio_layer=1, n_text_layer=1, n_vocab=100)
+    w = W.random_whisper_weights(dims, 0)
+    assert W.dims_from_openai_state_dict(w) == dims
+    hf = {}
+    back = {"query": "q_proj", "key": "k_proj", "value": "v_proj", "out": "out_proj"}
+    for k, v in w.items():
+        parts = k.split(".")
+        if k.startswith("encoder.conv"):
+            hf["model." + k] = v
+        elif k.startswith("encoder.ln_post"):
+            hf["model.encoder.layer_norm." + parts[-1]] = v
+        elif k.startswith("decoder.ln."):
+            hf["model.decoder.layer_norm." + parts[-1]] = v
+        elif k == "decoder.token_embedding.weight":
+            hf["model.decoder.embed_tokens.weight"] = v
+            hf["proj_out.weight"] = v
+        elif k == "decoder.positional_embedding":
+            hf["model.decoder.embed_positions.weight"] = v
+        else:
+            base = "model.%s.layers.%s." % (parts[0], parts[2])
+            mod = parts[3]
+            if mod in ("attn", "cross_attn"):
+                hf[base + ("self_attn" if mod == "attn" else "encoder_attn") + "." + back[parts[4]] + "." + parts[5]] = v
+            elif mod == "attn_ln":
+                hf[base + "self_attn_layer_norm." + parts[4]] = v
+            elif mod == "cross_attn_ln":
+                hf[base + "encoder_attn_layer_norm." + parts[4]] = v
+            elif mod == "mlp_ln":
+                hf[base + "final_layer_norm." + parts[4]] = v
+            else:
+                hf[base + ("fc1." if parts[4] == "0" else "fc2.") + parts[5]] = v
+    conv = W.from_hf_state_dict(hf)
+    assert set(conv) == set(w)
+    assert all(torch.equal(conv[k], w[k]) for k in w)
+    keras = {k: (v.numpy().T if (k.endswith(".weight") and v.dim() == 2 and "embedding" not in k)
+                 else (np.transpose(v.numpy(), (2, 1, 0)) if v.dim() == 3 else v.numpy())) for k, v in w.items()}
+    rt = W.from_keras_layout(keras)
+    assert all(np.array_equal(rt[k], w[k].numpy()) for k in w)
+
+
+def test_vocabulary_ids():
+    from speech_to_text_amd.stt.whisper import WhisperVocabulary, LANGUAGES
+    v = WhisperVocabulary()
+    assert len(LANGUAGES) == 99 and v.lang_to_idx["en"] == 50259 and v.lang_to_idx["fr"] == 50265
+    assert v.transcribe_token_idx == 50359 and v.timestamp_begin_idx == 50364
