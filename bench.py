@@ -34,6 +34,11 @@ def parse():
     ap.add_argument("--hours", type=float, default=1.0, help="audio hours per rank and step")
     ap.add_argument("--n-mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="large-v3", help="whisper leg / workload: model size")
+    ap.add_argument("--batch", type=int, default=32, help="whisper: 30 s windows per step and GPU")
+    ap.add_argument("--new-tokens", type=int, default=128)
+    ap.add_argument("--whisper-steps", type=int, default=2,
+                    help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
     return ap.parse_args()
 
 
@@ -158,14 +163,116 @@ def bench_logmel(args, rank, world):
     return line
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16
+
+
+def whisper_flops(dims, batch, new_tokens, prompt_len):
+    """Algorithmic FLOPs (2 per multiply-add) of one step: encoder + cross-K/V + decode."""
+    d, L, T, M = dims["n_audio_state"], dims["n_audio_layer"], 1500, dims["n_mels"]
+    stem = 2 * 3000 * 3 * M * d + 2 * T * 3 * d * d
+    layer = 2 * T * (4 * d * d + 8 * d * d) + 4 * T * T * d
+    enc = stem + L * layer
+    cross = dims["n_text_layer"] * 2 * T * 2 * d * d
+    tok = dims["n_text_layer"] * (2 * (4 * d * d + 2 * d * d + 8 * d * d) + 4 * T * d) + 2 * d * dims["n_vocab"]
+    return batch * enc, batch * cross, batch * tok * (new_tokens + prompt_len - 1)
+
+
+def bench_whisper(args, rank, world, steps, warmup, with_cpu):
+    """Whisper greedy over `batch` synthetic 30 s windows per step: PCM (resident in HBM) ->
+    log-mel -> encoder -> cross K/V -> `new_tokens` greedy tokens, early stopping off (random
+    weights never emit EOS reliably).  BASELINE.json configs[3] per GPU (configs[2] with
+    --model base)."""
+    from speech_to_text_amd.audio.stft import WhisperSTFT
+    from speech_to_text_amd.engine import WhisperEngine, whisper_dims
+    from speech_to_text_amd.weights import random_whisper_weights
+
+    dims = whisper_dims(args.model)
+    weights = random_whisper_weights(dims, 0)
+    prompt_row = [50258, 50259, 50359]
+    eng = WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
+                        max_text_len=args.new_tokens + len(prompt_row) + 1, max_prompt_len=4)
+    fn = WhisperSTFT(n_mel_channels=dims["n_mels"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(100 + rank)
+    pcm = torch.from_numpy(rng.uniform(-1, 1, args.batch * 480000).astype(np.float32)).to(dev)
+    prompt = np.array([prompt_row] * args.batch, dtype=np.int32)
+
+    def step():
+        mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])       # 30 s = 3000 frames exactly
+        eng.encode(mel)
+        return eng.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
+                            early_stopping=False)
+
+    for _ in range(warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        toks, lens, _ = step()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+
+    # encoder alone (MFMA-bound part), event-timed on the launching stream
+    mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record(); eng.encode(mel); b.record()
+    torch.cuda.synchronize()
+    enc_ms = a.elapsed_time(b)
+    f_enc, f_cross, f_dec = whisper_flops(dims, args.batch, args.new_tokens, len(prompt_row))
+    audio_s = world * steps * args.batch * 30.0
+    out = {
+        "metric": "audio-sec transcribed/sec, whisper-%s greedy" % args.model,
+        "value": round(audio_s / dt, 1), "unit": "audio-s/s", "n_gpus": world, "steps": steps,
+        "ms_per_step": round(dt / steps * 1e3, 2),
+        "config": {"workload": "whisper-%s greedy, %d x 30 s synthetic windows per GPU and step, "
+                   "%d new tokens, bf16" % (args.model, args.batch, args.new_tokens)},
+        "dtype": "bf16", "data": "synthetic",
+        "encoder_ms": round(enc_ms, 2),
+        "roofline_encoder": {"bound": "mfma", "achieved": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12, 1),
+                             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                             "scope": "whole encoder pass + cross K/V (all kernels), algorithmic FLOPs"},
+        "decode_ms_per_token": round((dt / steps * 1e3 - enc_ms) / args.new_tokens, 3),
+        "tokens_generated_per_window": int(lens[0]),
+    }
+    if with_cpu and rank == 0 and world == 1:
+        from oracle import model as om
+        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        torch.set_num_threads(threads)
+        odims = om.Dims(**{k: dims[k] for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head",
+                                                "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
+                                                "n_text_head", "n_text_layer")})
+        oracle = om.Whisper(odims, weights)
+        mel1 = mel[:1].cpu()
+        n_tok = 8
+        with torch.no_grad():
+            t = time.perf_counter()
+            ref = om.greedy(oracle, mel1, torch.tensor([prompt_row]), max_new_tokens=n_tok, eos=50257,
+                            pad=50257, early_stopping=False)
+            cpu_s = time.perf_counter() - t
+        # extrapolate the decode part to new_tokens tokens: report the measured sample as is
+        out["cpu_baseline"] = {"value": round(30.0 / cpu_s, 3), "unit": "audio-s/s", "cores": threads,
+                               "kind": "port", "seconds": round(cpu_s, 2),
+                               "sample": "1 window, encoder + %d greedy tokens (not %d), torch-CPU fp32 "
+                               "restatement (oracle/model.py) on the same weights" % (n_tok, args.new_tokens),
+                               "first_tokens_match_gpu": bool((ref["tokens"][0].numpy() == toks[0][:n_tok]).all())}
+    del eng
+    return out
+
+
 def main():
     args = parse()
     rank, world, local = init_dist(args.gpus)
     if args.workload == "logmel":
         line = bench_logmel(args, rank, world)
+        if args.whisper_steps > 0:
+            line["whisper"] = bench_whisper(args, rank, world, args.whisper_steps, 1,
+                                            not args.no_cpu_baseline)
     else:
-        from speech_to_text_amd import bench_model
-        line = bench_model.run(args, rank, world, barrier, max_over_ranks)
+        w = bench_whisper(args, rank, world, args.steps, args.warmup, not args.no_cpu_baseline)
+        line = dict(w, warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -48,6 +48,9 @@ def load():
             raise ImportError(
                 "%s not found: build it with `make -C %s` (hipcc, gfx950)"
                 % (LIB_PATH, os.path.join(_HERE, "csrc")))
+        # torch ships its own HIP runtime; it has to be the one already in the process when this
+        # library's libamdhip64 dependency is resolved, or the two runtimes disagree about devices
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
         _lib = lib
