@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstt_mi355x.so")
+LIB_PATH = os.environ.get("STT_MI355X_LIB", os.path.join(_HERE, "libstt_mi355x.so"))
 
 _c = ctypes
 _lib = None

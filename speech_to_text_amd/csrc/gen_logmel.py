@@ -453,7 +453,11 @@ def main():
             b = bins[k]
             emit("    {")
             emit("      const v2f br = %s, bi = %s;" % (rname(b.re), rname(b.im)))
-            emit("      const float c = ct[OFF_TW + %d], s = ct[OFF_TW + %d];" % (2 * k, 2 * k + 1))
+            if LITERALS & 2:
+                ang = 2.0 * math.pi * k / N_FFT
+                emit("      const float c = %s, s = %s;" % (_lit(math.cos(ang)), _lit(math.sin(ang))))
+            else:
+                emit("      const float c = ct[OFF_TW + %d], s = ct[OFF_TW + %d];" % (2 * k, 2 * k + 1))
             emit("      const float tr = c * br.y + s * bi.y, ti = c * bi.y - s * br.y;")
             emit("      const float ar = br.x + tr, ai = bi.x + ti;")
             emit("      mag[%d] = park(ar * ar + ai * ai);" % k)
@@ -493,19 +497,20 @@ def main():
     emit("// Pass A.  base = this lane's frame start in LDS (rows of 164 floats).  Writes the")
     emit("// eight 25-point sub-DFTs: parked in accumulator registers (ag) or kept (sv).")
     emit("__device__ __forceinline__ void logmel_pass_a(const unsigned char* base, "
-         "const float* __restrict__ ct, float (&ag)[LOGMEL_N_AG], v2f (&sv)[LOGMEL_N_SV]) {")
+         "lm_const_ptr ct, float (&ag)[LOGMEL_N_AG], v2f (&sv)[LOGMEL_N_SV]) {")
     out.extend(body_a)
     emit("}")
     emit("")
     emit("// Pass B: twiddles, 8-point DFTs, E/O combine; mag[k] = |X[k]|^2 (parked), k = 0..200.")
-    emit("__device__ __forceinline__ void logmel_pass_b(const float* __restrict__ ct, "
+    emit("__device__ __forceinline__ void logmel_pass_b(lm_const_ptr ct, "
          "const float (&ag)[LOGMEL_N_AG], const v2f (&sv)[LOGMEL_N_SV], float (&mag)[201]) {")
     out.extend(body_b)
     emit("}")
     emit("")
     for n_mels, pairs, off in ((80, pairs80, "OFF_MEL80"), (128, pairs128, "OFF_MEL128")):
+        fb = mel_filterbank(16000, N_FFT, n_mels, 0.0, 8000.0)
         emit("__device__ __forceinline__ void logmel_project_%d(const float (&mag)[201], "
-             "const float* __restrict__ ct, float (&mel)[%d]) {" % (n_mels, n_mels))
+             "lm_const_ptr ct, float (&mel)[%d]) {" % (n_mels, n_mels))
         i = 0
         defined = set()
         for m in range(n_mels):
@@ -518,7 +523,10 @@ def main():
                     # pads that hazard only for its own instructions)
                     emit("  const float m%d = __builtin_amdgcn_sqrtf(unpark(mag[%d]));" % (k, k))
                     defined.add(k)
-                terms.append("ct[%s + %d] * m%d" % (off, i, k))
+                if LITERALS & 4:
+                    terms.append("%s * m%d" % (_lit(fb[k, m]), k))
+                else:
+                    terms.append("ct[%s + %d] * m%d" % (off, i, k))
                 i += 1
             emit("  mel[%d] = %s;" % (m, " + ".join(terms)))
         emit("}")
@@ -552,8 +560,14 @@ def main():
           % (sum(1 for n in live if g.nodes[n][0] != "in"), n_fft_consts, table_len, n_ag, n_sv, err))
 
 
+def _lit(v):
+    return "%.9ef" % float(np.float32(v))
+
+
 def _fmt_node(g, n, off_fft):
     op, a, b, c = g.nodes[n]
+    if op == "mul" and LITERALS & 1:
+        return "  const v2f t%d = t%d * %s;" % (n, a, _lit(g.consts[c]))
     if op == "add":
         return "  const v2f t%d = t%d + t%d;" % (n, a, b)
     if op == "sub":
@@ -564,6 +578,7 @@ def _fmt_node(g, n, off_fft):
 
 
 N_SUBS_IN_AGPR = 5
+LITERALS = int(os.environ.get("LOGMEL_LITERALS", "0"))   # 1 fft constants, 2 twiddles, 4 mel weights
 PASS_A_ORDER = [(0,), (2,), (4,), 6, 7]     # (j,) = the pair j, j+1 from one 16-byte load
 
 

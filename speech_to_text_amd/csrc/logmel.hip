@@ -25,6 +25,7 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(4)))* lm_const_ptr;   // scalar-load (constant) view of the table
 
 // Park a value in / fetch it from the accumulator half of the register file.  With one
 // wave per SIMD a lane owns 256 VGPRs + 256 AGPRs; the 400 floats that live between the two
@@ -124,13 +125,13 @@ __device__ __forceinline__ void patch_reflect(const float* __restrict__ pcm, lon
 }
 
 template <int NMELS>
-__device__ __forceinline__ void project(const float (&mag)[201], const float* __restrict__ ct,
+__device__ __forceinline__ void project(const float (&mag)[201], lm_const_ptr ct,
                                         float (&mel)[NMELS]);
 template <>
-__device__ __forceinline__ void project<80>(const float (&mag)[201], const float* __restrict__ ct,
+__device__ __forceinline__ void project<80>(const float (&mag)[201], lm_const_ptr ct,
                                             float (&mel)[80]) { logmel_project_80(mag, ct, mel); }
 template <>
-__device__ __forceinline__ void project<128>(const float (&mag)[201], const float* __restrict__ ct,
+__device__ __forceinline__ void project<128>(const float (&mag)[201], lm_const_ptr ct,
                                              float (&mel)[128]) { logmel_project_128(mag, ct, mel); }
 
 struct LogmelArgs {
@@ -154,7 +155,9 @@ void logmel_main(const LogmelArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* __restrict__ ct = a.ct;
+  // the table is read through the constant address space so every access is a scalar load
+  // (a plain global pointer is demoted to per-lane vector loads once the loop also stores)
+  const lm_const_ptr ct = (lm_const_ptr)(unsigned long long)a.ct;
 
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
@@ -178,7 +181,11 @@ void logmel_main(const LogmelArgs a) {
     logmel_pass_a(lds + tid * (LM_PITCH * 4), ct, ag, sv);
     __syncthreads();                        // LDS may now be refilled
     const int next = tile + gridDim.x;
+#ifndef LM_ABLATE_DMA
     if (next < a.n_tiles)
+#else
+    if (next < a.n_tiles && a.n_tiles < 0)
+#endif
       issue_tile_dma(a.pcm, a.origin, a.lo, a.hi_al,
                      (a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200, lds, wave, lane);
 
@@ -198,7 +205,11 @@ void logmel_main(const LogmelArgs a) {
       zmin = fminf(zmin, z);
       mel[m] = z;
     }
+#ifdef LM_ABLATE_STORE
+    if (valid && mel[0] == 12345.678f) {
+#else
     if (valid) {
+#endif
       v4f* dst = (v4f*)(a.out + row * NMELS);
 #pragma unroll
       for (int m = 0; m < NMELS; m += 4) dst[m / 4] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
