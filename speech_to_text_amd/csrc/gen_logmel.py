@@ -449,24 +449,73 @@ def main():
                 emit("    const v2f t%d = sv[%d];" % (n, slot))
         for n in nodes:
             emit("  " + _fmt_node(g, n, OFF_FFT))
-        for k in fam_of_bin[k2]:
-            b = bins[k]
-            emit("    {")
-            emit("      const v2f br = %s, bi = %s;" % (rname(b.re), rname(b.im)))
-            if LITERALS & 2:
-                ang = 2.0 * math.pi * k / N_FFT
-                emit("      const float c = %s, s = %s;" % (_lit(math.cos(ang)), _lit(math.sin(ang))))
+        # X[k] = E + W^k O and |X[200-k]| = |E - W^k O| with W = exp(-2 pi i / 400); br/bi hold
+        # (E, O) in their two halves and cs = (cos, sin) of 2 pi k / 400.  Six packed
+        # instructions per bin, with operand-half selects and sign modifiers chosen by hand:
+        #   t  = (c O.re, s O.re)
+        #   T  = (s O.im + t.lo, c O.im - t.hi)            = W^k O
+        #   R  = (E.re + T.re, E.re - T.re),  I = (E.im + T.im, E.im - T.im)
+        #   M  = R R + I I                                 = (|X[k]|^2, |X[200-k]|^2)
+        # Two bins share one asm statement with their instructions interleaved: a packed result
+        # may not be consumed by the very next instruction, and the compiler does not pad
+        # hazards inside (or right after) an asm statement.
+        def neg(mask3):
+            return "[%s]" % ",".join(str(int(x)) for x in mask3)
+
+        def bin_instrs(tag, sr, si):
+            nr, ni = sr < 0, si < 0
+            return [
+                "v_pk_mul_f32 %%[t%s], %%[cs%s], %%[br%s] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:%s neg_hi:%s"
+                % (tag, tag, tag, neg((0, nr)), neg((0, nr))),
+                "v_pk_fma_f32 %%[t%s], %%[cs%s], %%[bi%s], %%[t%s] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:%s neg_hi:%s"
+                % (tag, tag, tag, tag, neg((0, ni, 0)), neg((0, ni, 1))),
+                "v_pk_add_f32 %%[m%s], %%[br%s], %%[t%s] op_sel:[0,0] op_sel_hi:[0,0] neg_lo:%s neg_hi:%s"
+                % (tag, tag, tag, neg((nr, 0)), neg((nr, 1))),
+                "v_pk_add_f32 %%[i%s], %%[bi%s], %%[t%s] op_sel:[0,1] op_sel_hi:[0,1] neg_lo:%s neg_hi:%s"
+                % (tag, tag, tag, neg((ni, 0)), neg((ni, 1))),
+                "v_pk_mul_f32 %%[m%s], %%[m%s], %%[m%s]" % (tag, tag, tag),
+                "v_pk_fma_f32 %%[m%s], %%[i%s], %%[i%s], %%[m%s]" % (tag, tag, tag, tag),
+            ]
+
+        def val(r):
+            return "v2f{0.f, 0.f}" if r.zero else "t%d" % r.n
+
+        ks = fam_of_bin[k2]
+        for g0 in range(0, len(ks), 2):
+            grp = ks[g0:g0 + 2]
+            lines = ["s_nop 0"]      # the inputs may come straight from a packed instruction
+            seqs = [bin_instrs("ab"[i], 1 if bins[k].re.zero else bins[k].re.s,
+                               1 if bins[k].im.zero else bins[k].im.s) for i, k in enumerate(grp)]
+            if len(grp) == 2:
+                for x, y in zip(*seqs):
+                    lines += [x, y]
+                lines.append("s_nop 0")
             else:
-                emit("      const float c = ct[OFF_TW + %d], s = ct[OFF_TW + %d];" % (2 * k, 2 * k + 1))
-            emit("      const float tr = c * br.y + s * bi.y, ti = c * bi.y - s * br.y;")
-            emit("      const float ar = br.x + tr, ai = bi.x + ti;")
-            emit("      mag[%d] = park(ar * ar + ai * ai);" % k)
-            if k < 100:
-                emit("      const float dr = br.x - tr, di = bi.x - ti;")
-                emit("      mag[%d] = park(dr * dr + di * di);" % (200 - k))
+                for x in seqs[0]:
+                    lines += [x, "s_nop 0"]
+            emit("    {")
+            outs, ins = [], []
+            for i, k in enumerate(grp):
+                tag = "ab"[i]
+                emit("      v2f m%s, t%s, i%s;" % (tag, tag, tag))
+                outs += ['[m%s] "=&v"(m%s)' % (tag, tag), '[t%s] "=&v"(t%s)' % (tag, tag),
+                         '[i%s] "=&v"(i%s)' % (tag, tag)]
+                ins += ['[cs%s] "s"(v2f{ct[OFF_TW + %d], ct[OFF_TW + %d]})' % (tag, 2 * k, 2 * k + 1),
+                        '[br%s] "v"(%s)' % (tag, val(bins[k].re)), '[bi%s] "v"(%s)' % (tag, val(bins[k].im))]
+            emit('      asm("%s"' % "\\n\\t".join(lines))
+            emit("          : %s" % ", ".join(outs))
+            emit("          : %s);" % ", ".join(ins))
+            for i, k in enumerate(grp):
+                tag = "ab"[i]
+                emit("      mag[%d] = park(m%s.x);" % (k, tag))
+                if k < 100:
+                    emit("      mag[%d] = park(m%s.y);" % (200 - k, tag))
             emit("    }")
         emit("  }")
         emit("  __builtin_amdgcn_sched_barrier(0);")
+        emit("  slot(%d);" % k2)
+        if os.environ.get("LM_SLOT_BARRIER", "1") == "1":
+            emit("  __builtin_amdgcn_sched_barrier(0);")
 
     n_fft_consts = len(g.consts)
     off_fft = 0
@@ -502,8 +551,11 @@ def main():
     emit("}")
     emit("")
     emit("// Pass B: twiddles, 8-point DFTs, E/O combine; mag[k] = |X[k]|^2 (parked), k = 0..200.")
+    emit("// slot(k2) is called after family k2 (13 calls): the caller's hook for work to interleave.")
+    emit("template <class Slot>")
     emit("__device__ __forceinline__ void logmel_pass_b(lm_const_ptr ct, "
-         "const float (&ag)[LOGMEL_N_AG], const v2f (&sv)[LOGMEL_N_SV], float (&mag)[201]) {")
+         "const float (&ag)[LOGMEL_N_AG], const v2f (&sv)[LOGMEL_N_SV], float (&mag)[201], "
+         "Slot&& slot) {")
     out.extend(body_b)
     emit("}")
     emit("")

@@ -73,28 +73,67 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-// Issue this wave's share of the LDS-DMA that brings one tile's PCM span in.
-// LDS piece q (16 B) = row q / 41, piece q % 41 of that row; the pad piece of a
-// row re-reads the row's last data piece.  g0 = clip index of the tile's first
-// sample.  Source indices are clamped into [lo, hi_al) (both multiples of 4 away
-// from pcm[0], so every piece is a 16-byte aligned load); what lies outside is
-// repaired by patch_reflect().
-__device__ __forceinline__ void issue_tile_dma(const float* __restrict__ pcm, long origin,
-                                               long lo, long hi_al, long g0, unsigned char* lds,
-                                               int wave, int lane) {
+// Issue instructions [i0, i1) of this wave's share (LM_DMA_PER_WAVE in all) of the LDS-DMA
+// that brings one tile's PCM span in.  LDS piece q (16 B) = row q / 41, piece q % 41 of that
+// row; the pad piece of a row re-reads the row's last data piece.  g0r = index, relative to
+// pcm[0], of the tile's first sample (may be negative); source indices are clamped into
+// [0, hi_r - 4] (hi_r a multiple of 4, so every piece is a 16-byte aligned load); what lies
+// outside is repaired by patch_reflect().
+__device__ __forceinline__ void issue_tile_dma(const float* __restrict__ pcm, int g0r, int hi_r,
+                                               unsigned char* lds, int wave, int lane, int i0,
+                                               int i1) {
 #pragma unroll 4
-  for (int i = 0; i < LM_DMA_PER_WAVE; ++i) {
+  for (int i = i0; i < i1; ++i) {
     const int inst = wave + 4 * i;
     const int q = inst * 64 + lane;
     const int r = q / LM_CHUNKS_PER_ROW;
     int cc = q - r * LM_CHUNKS_PER_ROW;
     cc = cc > 39 ? 39 : cc;
-    long s = g0 + (long)r * LM_HOP + 4 * cc;
-    s = s > hi_al - 4 ? hi_al - 4 : s;
-    s = s < lo ? lo : s;
-    __builtin_amdgcn_global_load_lds((glb_void*)(pcm + (s - origin)), (lds_void*)(lds + inst * 1024),
-                                     16, 0, 0);
+    int s = g0r + r * LM_HOP + 4 * cc;
+    s = s > hi_r - 4 ? hi_r - 4 : s;
+    s = s < 0 ? 0 : s;
+    // uniform base + 32-bit lane offset: one address register per instruction
+    __builtin_amdgcn_global_load_lds((glb_void*)((const char*)pcm + (unsigned)(s * 4)),
+                                     (lds_void*)(lds + inst * 1024), 16, 0, 0);
   }
+}
+
+// The same transfer for a tile whose span, plus one row of slack, lies inside [0, hi_r): one
+// instruction per LDS row, rows wave, wave + 4, ...  An instruction covers 1024 LDS bytes, a
+// row 656, so lanes 41..63 land on pieces 0..22 of the following row and fetch exactly the
+// samples that belong there (lane 40 fills the pad piece); whichever instruction writes a
+// byte last writes the same value.  Source and destination are uniform per instruction, so
+// issuing costs scalar work only, which is what lets the main loop drip the transfer in
+// between its register-starved compute sections.  The last instalments clamp to the last row.
+#define LM_ROW_DMA_PER_WAVE ((LM_ROWS + 3) / 4)
+#ifndef LM_DMA_PARTS
+#define LM_DMA_PARTS 4
+#endif
+struct RowDma {
+  const char* base;     // uniform: &pcm[g0r + wave * 160]
+  unsigned lds0;        // uniform: LDS byte address of row `wave`
+  unsigned lane_off;    // per lane: source byte offset inside the instruction
+};
+__device__ __forceinline__ void issue_rows_dma(const RowDma& d, int wave, int i0, int i1) {
+#pragma unroll
+  for (int i = i0; i < i1; ++i) {
+    int di = 4 * i;                              // rows past this wave's first
+    if (4 * i + 3 >= LM_ROWS) di = min(di, LM_ROWS - 1 - wave);
+    __builtin_amdgcn_global_load_lds((glb_void*)(d.base + (long)di * (LM_HOP * 4) + d.lane_off),
+                                     (lds_void*)(size_t)(d.lds0 + di * (LM_PITCH * 4)), 16, 0, 0);
+  }
+}
+
+// s_waitcnt immediates (vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+#define LM_WAIT_VM0 0x0F70      // vector memory (incl. LDS-DMA) drained
+#define LM_WAIT_LGKM0 0xC07F    // LDS / scalar loads drained
+
+// Workgroup barrier without the memory-model fences of __syncthreads(): the loop below
+// orders its LDS traffic itself and must not wait for output stores still in flight.
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // Reflect padding (np.pad mode='reflect', stft.py:251-255): the samples before
@@ -148,7 +187,11 @@ struct LogmelArgs {
   float* seg_min;        // [n_tiles * 4]
 };
 
-template <int NMELS>
+// BULK: the piece is long enough (host-checked: hi_al - origin >= (LM_ROWS + 1) * 160) for the
+// branch-free row transfer.  It always reads a span that lies inside the piece: for a tile at
+// either end of the piece the span is shifted inward, the rows it brings are wrong, and the
+// tile is fetched again, clamped lane by lane, when its turn comes (two tiles per piece).
+template <int NMELS, bool BULK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void logmel_main(const LogmelArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LM_LDS_BYTES];
@@ -161,36 +204,57 @@ void logmel_main(const LogmelArgs a) {
 
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
-  issue_tile_dma(a.pcm, a.origin, a.lo, a.hi_al,
-                 (a.frame_begin + (long)tile * LM_TILE_FRAMES) * LM_HOP - 200, lds, wave, lane);
+  const int hi_r = (int)(a.hi_al - a.origin);
+  issue_tile_dma(a.pcm, (int)((a.frame_begin + (long)tile * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin),
+                 hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
+  __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
 
   float run_max = -__builtin_inff();
   while (tile < a.n_tiles) {
     const long t0 = a.frame_begin + (long)tile * LM_TILE_FRAMES;
     const long g0 = t0 * LM_HOP - 200;
-    __builtin_amdgcn_s_waitcnt(0);          // this wave's DMA pieces have landed
-    __syncthreads();                        // ... and everyone else's
-    if (g0 < 0 || g0 + (long)LM_ROWS * LM_HOP > a.hi_al) {   // block-uniform
+    block_barrier();                        // every wave's DMA pieces of this tile have landed
+    if (g0 < 0 || g0 + (long)(LM_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
+      if (BULK) {
+        issue_tile_dma(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
+        __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
+        block_barrier();
+      }
       patch_reflect(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
-      __syncthreads();
+      __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+      block_barrier();
     }
 
     // pass A straight from LDS: sample n of this lane's frame sits at row tid + n/160, col n%160
     float ag[LOGMEL_N_AG];
     v2f sv[LOGMEL_N_SV];
     logmel_pass_a(lds + tid * (LM_PITCH * 4), ct, ag, sv);
-    __syncthreads();                        // LDS may now be refilled
+    __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+    block_barrier();                        // LDS may now be refilled
     const int next = tile + gridDim.x;
-#ifndef LM_ABLATE_DMA
-    if (next < a.n_tiles)
-#else
-    if (next < a.n_tiles && a.n_tiles < 0)
-#endif
-      issue_tile_dma(a.pcm, a.origin, a.lo, a.hi_al,
-                     (a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200, lds, wave, lane);
-
+    int g0r_next = (int)((a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin);
+    if (!BULK && next < a.n_tiles)
+      issue_tile_dma(a.pcm, g0r_next, hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
+    // BULK: the next tile's rows are requested in LM_DMA_PARTS instalments between the families
+    // of pass B, so the wave never sits behind a full memory queue.  An instalment is straight
+    // scalar code rebuilt from scratch each time: nothing extra stays live across the
+    // register-starved compute sections and pass B remains a single basic block.  (Past the
+    // last tile it fetches a span nobody reads.)
+    g0r_next = min(max(g0r_next, 0), hi_r - (LM_ROWS + 1) * LM_HOP);
     float mag[201];
-    logmel_pass_b(ct, ag, sv, mag);
+    logmel_pass_b(ct, ag, sv, mag, [&](int k2) __attribute__((always_inline)) {
+      constexpr int kEvery = 13 / LM_DMA_PARTS;
+      if (BULK && k2 % kEvery == 0 && k2 / kEvery < LM_DMA_PARTS) {
+        const int part = k2 / kEvery;
+        RowDma rd;
+        rd.base = (const char*)a.pcm + ((long)g0r_next + wave * LM_HOP) * 4;
+        rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * (LM_PITCH * 4);
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+        rd.lane_off = ln * 16 - (ln >= 40 ? 16 : 0);
+        issue_rows_dma(rd, wave, (LM_ROW_DMA_PER_WAVE * part) / LM_DMA_PARTS,
+                       (LM_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
+      }
+    });
     float mel[NMELS];
     project<NMELS>(mag, ct, mel);
 
@@ -205,14 +269,24 @@ void logmel_main(const LogmelArgs a) {
       zmin = fminf(zmin, z);
       mel[m] = z;
     }
+    // the DMA issued above landed long ago; waiting here, before the stores, leaves the stores
+    // in flight across the loop edge (the counter cannot tell loads from stores)
+    __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
+    asm volatile("" ::: "memory");
 #ifdef LM_ABLATE_STORE
-    if (valid && mel[0] == 12345.678f) {
+    if (valid && zmin == 12345.678f) {
 #else
     if (valid) {
 #endif
+#ifdef LM_ABLATE_COALESCED
+      v4f* dst = (v4f*)(a.out + ((long)tile * LM_TILE_FRAMES + (tid & ~63)) * NMELS) + lane;
+#pragma unroll
+      for (int m = 0; m < NMELS; m += 4) dst[(m / 4) * 64] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
+#else
       v4f* dst = (v4f*)(a.out + row * NMELS);
 #pragma unroll
       for (int m = 0; m < NMELS; m += 4) dst[m / 4] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
+#endif
     } else {
       ymax = -__builtin_inff();
       zmin = __builtin_inff();
@@ -360,6 +434,9 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
   const long lo = sample_origin, hi = sample_origin + n_local < n_total ? sample_origin + n_local : n_total;
   if (sample_origin & 3)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "sample_origin must be a multiple of 4");
+  if (n_local > (int64_t)2000000000)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "pcm piece of %lld samples: at most 2e9 per call",
+                    (long long)n_local);
   if (sample_origin < 0 || lo > need_lo || hi < need_hi || hi - lo < 8)
     return stt_fail(STT_ERR_INVALID_ARGUMENT,
                     "pcm piece [%ld, %ld) does not cover the samples [%ld, %ld) its frames read", lo, hi,
@@ -378,10 +455,14 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
   a.seg_min = (float*)((char*)d_workspace + kWsHeader);
   const int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
   hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
-  if (plan->n_mels == 80)
-    hipLaunchKernelGGL(logmel_main<80>, dim3(grid), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL(logmel_main<128>, dim3(grid), dim3(256), 0, stream, a);
+  const bool bulk = a.hi_al - a.origin >= (long)(LM_ROWS + 1) * LM_HOP;
+  if (plan->n_mels == 80) {
+    if (bulk) hipLaunchKernelGGL((logmel_main<80, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logmel_main<80, false>), dim3(grid), dim3(256), 0, stream, a);
+  } else {
+    if (bulk) hipLaunchKernelGGL((logmel_main<128, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logmel_main<128, false>), dim3(grid), dim3(256), 0, stream, a);
+  }
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
 }
