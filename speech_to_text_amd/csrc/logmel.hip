@@ -209,11 +209,19 @@ void logmel_main(const LogmelArgs a) {
                  hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
   __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
 
+#ifdef LM_TIMING
+  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
+#define LM_TICK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define LM_TICK(i)
+#endif
   float run_max = -__builtin_inff();
   while (tile < a.n_tiles) {
     const long t0 = a.frame_begin + (long)tile * LM_TILE_FRAMES;
     const long g0 = t0 * LM_HOP - 200;
     block_barrier();                        // every wave's DMA pieces of this tile have landed
+    LM_TICK(0)
     if (g0 < 0 || g0 + (long)(LM_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
       if (BULK) {
         issue_tile_dma(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
@@ -228,9 +236,12 @@ void logmel_main(const LogmelArgs a) {
     // pass A straight from LDS: sample n of this lane's frame sits at row tid + n/160, col n%160
     float ag[LOGMEL_N_AG];
     v2f sv[LOGMEL_N_SV];
+    LM_TICK(1)
     logmel_pass_a(lds + tid * (LM_PITCH * 4), ct, ag, sv);
     __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+    LM_TICK(2)
     block_barrier();                        // LDS may now be refilled
+    LM_TICK(3)
     const int next = tile + gridDim.x;
     int g0r_next = (int)((a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin);
     if (!BULK && next < a.n_tiles)
@@ -255,6 +266,7 @@ void logmel_main(const LogmelArgs a) {
                        (LM_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
       }
     });
+    LM_TICK(4)
     float mel[NMELS];
     project<NMELS>(mag, ct, mel);
 
@@ -271,31 +283,71 @@ void logmel_main(const LogmelArgs a) {
     }
     // the DMA issued above landed long ago; waiting here, before the stores, leaves the stores
     // in flight across the loop edge (the counter cannot tell loads from stores)
+    LM_TICK(5)
     __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
     asm volatile("" ::: "memory");
-#ifdef LM_ABLATE_STORE
-    if (valid && zmin == 12345.678f) {
-#else
-    if (valid) {
-#endif
-#ifdef LM_ABLATE_COALESCED
-      v4f* dst = (v4f*)(a.out + ((long)tile * LM_TILE_FRAMES + (tid & ~63)) * NMELS) + lane;
-#pragma unroll
-      for (int m = 0; m < NMELS; m += 4) dst[(m / 4) * 64] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
-#else
-      v4f* dst = (v4f*)(a.out + row * NMELS);
-#pragma unroll
-      for (int m = 0; m < NMELS; m += 4) dst[m / 4] = v4f{mel[m], mel[m + 1], mel[m + 2], mel[m + 3]};
-#endif
-    } else {
+    LM_TICK(6)
+    if (!valid) {
       ymax = -__builtin_inff();
       zmin = __builtin_inff();
+    }
+    // Store.  A lane holds one whole output row, so a plain store instruction would touch 64
+    // rows with 16 bytes each, and the L2 request rate (one request per 16-byte piece) would
+    // cost more time than the transform.  The four lanes of a quad therefore first transpose
+    // 4 x 4 pieces among themselves (two butterfly steps of lane-pair exchanges per register),
+    // after which lane i of the quad holds pieces i of the quad's four rows: one store
+    // instruction then writes 64 contiguous bytes per quad, a quarter of the requests.
+    {
+      const bool hi1 = lane & 1, hi2 = lane & 2;
+      const long qrow = row - (lane & 3);              // first row of this quad
+      const int qtid = tid & ~3;
+#pragma unroll
+      for (int g = 0; g < NMELS; g += 16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float* r0 = &mel[g + c];                      // registers r0[4 j], j = piece index
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {              // exchange with lane ^ 1: pieces j, j + 1
+            const float send = hi1 ? r0[4 * j] : r0[4 * (j + 1)];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+                __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+            if (hi1) r0[4 * j] = recv; else r0[4 * (j + 1)] = recv;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {                 // exchange with lane ^ 2: pieces j, j + 2
+            const float send = hi2 ? r0[4 * j] : r0[4 * (j + 2)];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+                __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+            if (hi2) r0[4 * j] = recv; else r0[4 * (j + 2)] = recv;
+          }
+        }
+      }
+      // now mel[g + 4 j + c] = element (g + 4 (lane & 3) + c) of row qrow + j
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#ifdef LM_ABLATE_STORE
+        if (qtid + j < LM_TILE_FRAMES && qrow + j < a.frame_count && zmin == 12345.678f) {
+#else
+        if (qtid + j < LM_TILE_FRAMES && qrow + j < a.frame_count) {
+#endif
+          float* dst = a.out + (qrow + j) * NMELS + 4 * (lane & 3);
+#pragma unroll
+          for (int g = 0; g < NMELS; g += 16)
+            *(v4f*)(dst + g) = v4f{mel[g + 4 * j], mel[g + 4 * j + 1], mel[g + 4 * j + 2], mel[g + 4 * j + 3]};
+        }
+      }
     }
     run_max = fmaxf(run_max, ymax);
     zmin = wave_min(zmin);
     if (lane == 0) a.seg_min[tile * 4 + wave] = zmin;
     tile = next;
+    LM_TICK(7)
   }
+#ifdef LM_TIMING
+  if (blockIdx.x == 7 && lane == 0)
+    printf("wave %d: barrier %u  edge %u  passA %u  barrier %u  passB %u  project+log %u  dma-wait %u  stores %u\n",
+           wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7]);
+#endif
   run_max = wave_max(run_max);
   if (lane == 0 && run_max > -__builtin_inff()) atomic_max_float(a.piece_max, run_max);
 }
