@@ -382,8 +382,15 @@ def main():
         for i, n in enumerate(ins):
             a = g.nodes[n][1]
             n2 = (a - j) // 8
-            emit("    const v2f t%d = %s * v2f{ct[OFF_WIN + %d], ct[OFF_WIN + %d]};"
-                 % (n, loader(n2), 2 * a, 2 * a + 1))
+            if LITERALS & 8:
+                emit("    const v2f t%d = %s * v2f{%s, %s};"
+                     % (n, loader(n2), _lit(HANN[2 * a]), _lit(HANN[2 * a + 1])))
+            else:
+                # the window table is stored in the order pass A consumes it (sub-DFT j, then
+                # input n2), so one sub-DFT's 50 values are a few wide scalar loads
+                pos = 2 * (25 * (a % 8) + a // 8)
+                emit("    const v2f t%d = %s * v2f{ct[OFF_WIN + %d], ct[OFF_WIN + %d]};"
+                     % (n, loader(n2), pos, pos + 1))
         for n in nodes:
             if g.nodes[n][0] != "in":
                 emit("  " + _fmt_node(g, n, OFF_FFT))
@@ -630,6 +637,7 @@ def _fmt_node(g, n, off_fft):
 
 
 N_SUBS_IN_AGPR = 5
+HANN = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(400) / 400)).astype(np.float32)   # periodic Hann
 LITERALS = int(os.environ.get("LOGMEL_LITERALS", "0"))   # 1 fft constants, 2 twiddles, 4 mel weights
 PASS_A_ORDER = [(0,), (2,), (4,), 6, 7]     # (j,) = the pair j, j+1 from one 16-byte load
 

@@ -430,7 +430,11 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
 
   std::vector<float> table(LOGMEL_TABLE_LEN, 0.0f);
   for (int i = 0; i < LOGMEL_N_FFT_CONSTS; ++i) table[LOGMEL_OFF_FFT + i] = logmel_fft_consts[i];
-  for (int i = 0; i < LM_NFFT; ++i) table[LOGMEL_OFF_WIN + i] = window[i];
+  // window sample s = 2 a + h is input a / 8 of sub-DFT a % 8: stored in consumption order
+  for (int i = 0; i < LM_NFFT; ++i) {
+    const int a2 = i / 2;
+    table[LOGMEL_OFF_WIN + 2 * (25 * (a2 % 8) + a2 / 8) + (i & 1)] = window[i];
+  }
   for (int k = 0; k <= 100; ++k) {
     const double th = 2.0 * 3.14159265358979323846 * k / 400.0;
     table[LOGMEL_OFF_TW + 2 * k] = (float)cos(th);
