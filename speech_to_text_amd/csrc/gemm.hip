@@ -32,52 +32,54 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 
 // ---------------------------------------------------------------------------------------------
 // Large-M kernel: 128 x 128 x 64 block tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA tiles.
-// Global -> registers -> LDS with the next tile's loads in flight during the MFMAs; LDS rows are
-// 128 B with their 16-byte pieces XOR-swizzled by (row & 7) so fragment reads spread over banks.
+// One 32 KB LDS stage per block, filled by LDS-DMA (16 B per lane, no staging registers), two
+// barriers per K step; the block is small enough (32 KB LDS, < 128 VGPRs) for three or four to
+// share a CU, and it is the other blocks' MFMAs that cover a block's load latency.
+// LDS rows are 128 B (64 k values); the 16-byte piece c of row r sits at slot c ^ (r & 7), so the
+// sixteen rows a fragment read touches spread over all banks.  An LDS-DMA instruction writes
+// 1 KB = 8 whole rows in lane order (lane -> row lane / 8, slot lane % 8), so the swizzle is
+// applied on the source side: the lane fetches piece (lane % 8) ^ (lane / 8) of its row.
+// Blocks are renumbered so that the blocks an XCD runs (every 8th) walk neighbouring tiles and
+// share activation panels in that XCD's L2.
 // ---------------------------------------------------------------------------------------------
 #define GB_BM 128
 #define GB_BN 128
 #define GB_BK 64
 
+typedef __attribute__((address_space(3))) void gb_lds_void;
+typedef const __attribute__((address_space(1))) void gb_glb_void;
+
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (GB_BM + GB_BN) * GB_BK * 2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256, 3) void gemm_big_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[(GB_BM + GB_BN) * GB_BK * 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GB_BM, n0 = blockIdx.x * GB_BN;
+  // XCD-aware renumbering (bijective for any tile count): hardware block b runs on XCD b % 8
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int m0 = (tile / tiles_n) * GB_BM, n0 = (tile % tiles_n) * GB_BN;
   const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
   const bf16_t* __restrict__ W = g.w;
   const int M = g.m, N = g.n, K = g.k;
   const int nk = K / GB_BK;
+  constexpr int kBOff = GB_BM * GB_BK * 2;
 
-  constexpr int kStage = (GB_BM + GB_BN) * GB_BK * 2, kBOff = GB_BM * GB_BK * 2;
-
-  uint4 ra[4], rb[4];
-  long a_off[4], b_off[4];
-  int s_off[4];
+  // this lane's four source rows of A and of W (DMA instruction j = wave + 4 i covers rows 8j..8j+7)
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+  const int piece = (lane & 7) ^ (lane >> 3);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+    const int row = 8 * (wave + 4 * i) + (lane >> 3);
     int gm = m0 + row; gm = gm < M ? gm : M - 1;
     int gn = n0 + row; gn = gn < N ? gn : N - 1;
-    a_off[i] = (long)gm * g.lda + ch * 8;
-    b_off[i] = (long)gn * K + ch * 8;
-    s_off[i] = row * 128 + ((ch ^ (row & 7)) << 4);
+    a_src[i] = A + (long)gm * g.lda + piece * 8;
+    w_src[i] = W + (long)gn * K + piece * 8;
   }
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const uint4*)(A + a_off[i] + (long)kt * GB_BK);
-      rb[i] = *(const uint4*)(W + b_off[i] + (long)kt * GB_BK);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(smem + buf * kStage + s_off[i]) = ra[i];
-      *(uint4*)(smem + buf * kStage + kBOff + s_off[i]) = rb[i];
-    }
-  };
 
   f4_t acc[4][4];   // [tn][tm]
 #pragma unroll
@@ -85,13 +87,17 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
-  sstore(0);
-  __syncthreads();
   const int fr = lane & 15, fg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(a_src[i] + kt * GB_BK),
+                                       (gb_lds_void*)(smem + (wave + 4 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(w_src[i] + kt * GB_BK),
+                                       (gb_lds_void*)(smem + kBOff + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's pieces have landed
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf8_t wf[4], af[4];
@@ -99,9 +105,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int rw = wn * 64 + t * 16 + fr;
-        wf[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + cur * kStage + kBOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
+        wf[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + kBOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
         const int rm = wm * 64 + t * 16 + fr;
-        af[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + cur * kStage + rm * 128 + ((ch ^ (rm & 7)) << 4)));
+        af[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + rm * 128 + ((ch ^ (rm & 7)) << 4)));
       }
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn)
@@ -109,8 +115,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
         for (int tm = 0; tm < 4; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
+    __syncthreads();                        // everyone is done reading before the next fill
   }
 
   // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
@@ -160,13 +165,15 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs g) {
 }
 
 void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
-  dim3 grid((g.n + GB_BN - 1) / GB_BN, (g.m + GB_BM - 1) / GB_BM, g.batch > 0 ? g.batch : 1);
+  const int tiles_n = (g.n + GB_BN - 1) / GB_BN, tiles_m = (g.m + GB_BM - 1) / GB_BM;
+  const int n_tiles = tiles_n * tiles_m;
+  dim3 grid(n_tiles, 1, g.batch > 0 ? g.batch : 1);
   switch (epilogue) {
-    case EPI_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_BF16>, grid, dim3(256), 0, stream, g); break;
-    case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, stream, g); break;
-    case EPI_RESID_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_RESID_F32>, grid, dim3(256), 0, stream, g); break;
-    case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_POS_F32>, grid, dim3(256), 0, stream, g); break;
-    default: hipLaunchKernelGGL(gemm_big_kernel<EPI_F32>, grid, dim3(256), 0, stream, g); break;
+    case EPI_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_BF16>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    case EPI_RESID_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_RESID_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_POS_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    default: hipLaunchKernelGGL(gemm_big_kernel<EPI_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
   }
 }
 
