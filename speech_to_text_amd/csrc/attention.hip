@@ -229,22 +229,38 @@ void launch_attn_decoder_self(const SelfAttnArgs& a, hipStream_t stream) {
 // Decoder cross-attention: K/V of the encoder output are read once per (window, head) and step
 // for all the sequences of that window (its beams), in 1 KiB wave accesses (8 keys x 128 B).
 // Lane = (key group l >> 3, 16-byte piece l & 7).  Queries are handled CQ at a time.
+// The kernel is a pure HBM stream (384 KB per block and query group), so each wave keeps
+// CROSS_U independent 1 KiB loads in flight before it touches any of them; exp() is applied on
+// the fly in the P V pass (every lane of a key's 8-lane group recomputes the same weight), which
+// leaves two passes and two barriers per query group.
 // ---------------------------------------------------------------------------------------------
 #define CROSS_MAX_T 1536
+typedef __attribute__((ext_vector_type(4))) unsigned int cross_u4;
+
+// sum over the 8 lanes that share a key: xor 1, xor 2 inside the quad, then the mirrored quad
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
 template <int CQ>
 __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttnArgs a) {
+  constexpr int U = CQ == 1 ? 6 : CQ == 2 ? 4 : 2;     // loads in flight per wave
   __shared__ float sc[CQ][CROSS_MAX_T];
   __shared__ float qs[CQ][64];
   __shared__ float red[4][CQ][64];
-  __shared__ float stat[CQ][2];
+  __shared__ float wmax[4][CQ];
+  __shared__ float wsum[4][CQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int piece = lane & 7, kg = lane >> 3;
   const int h = blockIdx.x, win = blockIdx.y;
   const int d_model = a.heads * 64;
   const int nq_total = a.seq_per_win * a.s_new;
   const long row0 = (long)win * nq_total;          // first query row of this window
-  const bf16_t* kb = a.k + ((long)win * a.heads + h) * a.t_enc * 64;
-  const bf16_t* vb = a.v + ((long)win * a.heads + h) * a.t_enc * 64;
+  const bf16_t* kb = a.k + ((long)win * a.heads + h) * a.t_enc * 64 + 8 * piece;
+  const bf16_t* vb = a.v + ((long)win * a.heads + h) * a.t_enc * 64 + 8 * piece;
   const int T = a.t_enc;
 
   for (int qc = 0; qc < nq_total; qc += CQ) {
@@ -259,67 +275,95 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
     for (int qi = 0; qi < CQ; ++qi)
 #pragma unroll
       for (int e = 0; e < 8; ++e) qr[qi][e] = qs[qi][8 * piece + e];
-    // scores
-    for (int key = wave * 8 + kg; key < T; key += 32) {
-      const uint4 u = *(const uint4*)(kb + (long)key * 64 + 8 * piece);
-      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-      float kv[8];
+
+    // scores (and this thread's running maximum per query)
+    float mx[CQ];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(w[e] << 16); kv[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+    for (int qi = 0; qi < CQ; ++qi) mx[qi] = -__builtin_inff();
+    for (int k0 = wave * 8 + kg; k0 < T; k0 += 32 * U) {
+      cross_u4 u[U];
 #pragma unroll
-      for (int qi = 0; qi < CQ; ++qi) {
-        float s = 0.f;
+      for (int j = 0; j < U; ++j) {
+        const int key = k0 + 32 * j < T ? k0 + 32 * j : T - 1;
+        u[j] = __builtin_nontemporal_load((const cross_u4*)(kb + (long)key * 64));
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += kv[e] * qr[qi][e];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-        if (piece == 0) sc[qi][key] = s;
+      for (int j = 0; j < U; ++j) {
+        const int key = k0 + 32 * j;
+        float kv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(u[j][e] << 16); kv[2 * e + 1] = __uint_as_float(u[j][e] & 0xFFFF0000u); }
+#pragma unroll
+        for (int qi = 0; qi < CQ; ++qi) {
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sv += kv[e] * qr[qi][e];
+          sv = sum8(sv);
+          if (key < T) {
+            mx[qi] = fmaxf(mx[qi], sv);
+            if (piece == 0) sc[qi][key] = sv;
+          }
+        }
       }
     }
-    __syncthreads();
-    // softmax statistics: wave w handles queries w, w + 4
-    for (int qi = wave; qi < nq; qi += 4) {
-      float mx = -__builtin_inff();
-      for (int p = lane; p < T; p += 64) mx = fmaxf(mx, sc[qi][p]);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      float sum = 0.f;
-      for (int p = lane; p < T; p += 64) { const float e = __expf(sc[qi][p] - mx); sc[qi][p] = e; sum += e; }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      if (lane == 0) { stat[qi][0] = mx; stat[qi][1] = 1.0f / sum; }
+    for (int qi = 0; qi < CQ; ++qi) {
+      float m = mx[qi];
+      m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (lane == 0) wmax[wave][qi] = m;
     }
     __syncthreads();
-    // P V
-    float acc[CQ][8];
 #pragma unroll
     for (int qi = 0; qi < CQ; ++qi)
+      mx[qi] = fmaxf(fmaxf(wmax[0][qi], wmax[1][qi]), fmaxf(wmax[2][qi], wmax[3][qi]));
+
+    // P V with the weights exponentiated on the fly
+    float acc[CQ][8], sum[CQ];
+#pragma unroll
+    for (int qi = 0; qi < CQ; ++qi) {
+      sum[qi] = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
-    for (int key = wave * 8 + kg; key < T; key += 32) {
-      const uint4 u = *(const uint4*)(vb + (long)key * 64 + 8 * piece);
-      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-      float vv[8];
+    }
+    for (int k0 = wave * 8 + kg; k0 < T; k0 += 32 * U) {
+      cross_u4 u[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { vv[2 * e] = __uint_as_float(w[e] << 16); vv[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+      for (int j = 0; j < U; ++j) {
+        const int key = k0 + 32 * j < T ? k0 + 32 * j : T - 1;
+        u[j] = __builtin_nontemporal_load((const cross_u4*)(vb + (long)key * 64));
+      }
 #pragma unroll
-      for (int qi = 0; qi < CQ; ++qi) {
-        const float p = sc[qi][key];
+      for (int j = 0; j < U; ++j) {
+        const int key = k0 + 32 * j;
+        float vv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[qi][e] += p * vv[e];
+        for (int e = 0; e < 4; ++e) { vv[2 * e] = __uint_as_float(u[j][e] << 16); vv[2 * e + 1] = __uint_as_float(u[j][e] & 0xFFFF0000u); }
+#pragma unroll
+        for (int qi = 0; qi < CQ; ++qi) {
+          const float pw = key < T ? __expf(sc[qi][key] - mx[qi]) : 0.f;
+          sum[qi] += pw;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[qi][e] += pw * vv[e];
+        }
       }
     }
 #pragma unroll
-    for (int qi = 0; qi < CQ; ++qi)
+    for (int qi = 0; qi < CQ; ++qi) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = acc[qi][e];
         v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
         if (kg == 0) red[wave][qi][8 * piece + e] = v;
       }
+      float sm = sum[qi];
+      sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+      if (lane == 0) wsum[wave][qi] = sm;
+    }
     __syncthreads();
     for (int e = tid; e < nq * 64; e += 256) {
       const int qi = e >> 6, d = e & 63;
-      const float v = (red[0][qi][d] + red[1][qi][d] + red[2][qi][d] + red[3][qi][d]) * stat[qi][1];
+      const float inv = 1.0f / (wsum[0][qi] + wsum[1][qi] + wsum[2][qi] + wsum[3][qi]);
+      const float v = (red[0][qi][d] + red[1][qi][d] + red[2][qi][d] + red[3][qi][d]) * inv;
       a.out[(row0 + qc + qi) * d_model + h * 64 + d] = f2bf(v);
     }
     __syncthreads();

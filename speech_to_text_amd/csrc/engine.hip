@@ -4,6 +4,7 @@
 //
 // Reference call path replaced: Transformer.infer (architectures/transformers/
 // transformer_arch.py:1029-1065) = encoder once + generation_utils.infer (greedy / beam).
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,6 +36,8 @@ struct stt_engine {
   int max_batch = 0, max_beams = 0, max_len = 0, max_prompt = 0;
   int device = 0, n_cu = 256;
   bool finalized = false;
+  hipStream_t gen_stream = nullptr;    // generation runs here: a captured token step needs a real stream
+  hipEvent_t gen_event = nullptr;
   std::map<std::string, std::vector<float>> host_w;
   std::vector<void*> allocs;
 
@@ -232,7 +235,9 @@ int stt_engine_create(const stt_model_config* cfg, int max_batch, int max_beams,
 
 void stt_engine_destroy(stt_engine* e) {
   if (!e) return;
-  for (void* p : e->allocs) hipFree(p);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
+  if (e->gen_event) (void)hipEventDestroy(e->gen_event);
   delete e;
 }
 
@@ -501,6 +506,19 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   const int n_seq = batch * beams, V = e->cfg.n_vocab, max_steps = p->max_steps;
   GenState& gs = e->gs;
 
+  // Generation runs on the engine's own stream, ordered after the caller's: the token step is
+  // recorded once into a graph (every per-token quantity lives in device memory, so the
+  // recorded launches are the same for every token) and replayed, and the caller's stream may
+  // be the legacy default stream, which cannot be captured.
+  hipStream_t user_st = st;
+  if (!e->gen_stream) {
+    STT_HIP_OR_FAIL(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking), (void)0);
+    STT_HIP_OR_FAIL(hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming), (void)0);
+  }
+  STT_HIP_OR_FAIL(hipEventRecord(e->gen_event, user_st), (void)0);
+  st = e->gen_stream;
+  STT_HIP_OR_FAIL(hipStreamWaitEvent(st, e->gen_event, 0), (void)0);
+
   // prompt repeated for every beam (generation_utils.py:448-451)
   std::vector<int> tok((size_t)n_seq * prompt_len), pos((size_t)n_seq * prompt_len);
   for (int i = 0; i < n_seq; ++i)
@@ -515,6 +533,8 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   if (p->n_suppress_first)
     STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress_first, p->suppress_first, p->n_suppress_first * 4,
                                    hipMemcpyHostToDevice, st), (void)0);
+  // the pageable host buffers above must be consumed before they go out of scope or change
+  STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
   hipLaunchKernelGGL(init_state_kernel, dim3(n_seq), dim3(64), 0, st, gs, n_seq, prompt_len, e->max_len);
   hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, gs.generated, (long)n_seq * max_steps,
                      p->pad_token);
@@ -532,22 +552,44 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   int rc = decoder_pass(e, n_seq, beams, prompt_len, true, nullptr, st);
   if (rc) return rc;
   select(prompt_len);
+
+  // one token step = prepare inputs, decoder pass over one new token, selection
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  const char* no_graph = getenv("STT_MI355X_NO_GRAPH");
+  if (max_steps > 1 && !(no_graph && no_graph[0] == '1')) {
+    STT_HIP_OR_FAIL(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), (void)0);
+    launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
+    rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+    select(1);
+    const hipError_t cap = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    STT_HIP_OR_FAIL(cap, (void)0);
+    STT_HIP_OR_FAIL(hipGraphInstantiate(&step_exec, graph, nullptr, nullptr, 0), (void)hipGraphDestroy(graph));
+  }
+  auto drop_graph = [&]() {
+    if (step_exec) (void)hipGraphExecDestroy(step_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+  };
   const int check_every = p->check_every > 0 ? p->check_every : 8;
-  int steps_done = 1;
   for (int t = 1; t < max_steps; ++t) {
     if (p->early_stopping && (t % check_every) == 0) {
       int fin = 0;
-      STT_HIP_OR_FAIL(hipMemcpyAsync(&fin, gs.all_finished, 4, hipMemcpyDeviceToHost, st), (void)0);
-      STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
+      STT_HIP_OR_FAIL(hipMemcpyAsync(&fin, gs.all_finished, 4, hipMemcpyDeviceToHost, st), drop_graph());
+      STT_HIP_OR_FAIL(hipStreamSynchronize(st), drop_graph());
       if (fin) break;
     }
-    launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
-    rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
-    if (rc) return rc;
-    select(1);
-    ++steps_done;
+    if (step_exec) {
+      STT_HIP_OR_FAIL(hipGraphLaunch(step_exec, st), drop_graph());
+    } else {
+      launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
+      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+      if (rc) return rc;
+      select(1);
+    }
   }
-  (void)steps_done;
+  STT_HIP_OR_FAIL(hipStreamSynchronize(st), drop_graph());
+  drop_graph();
   // results: [batch][nsent][max_steps]; lengths exclude the prompt (generation_utils.py:293-300)
   std::vector<int> h_gen((size_t)n_seq * max_steps), h_len(n_seq);
   std::vector<float> h_sc(n_seq);
