@@ -158,17 +158,31 @@ void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_s
 // copying them; generation_utils.py:652-676 gathers the whole cache).  New tokens are appended
 // to the sequence's own slot.  Causal inside the new tokens (transformer_arch.py:186-195).
 // ---------------------------------------------------------------------------------------------
+// Lane = (key group l >> 3, 16-byte piece l & 7): one load instruction covers 8 keys x 128 B and
+// SELF_U of them are in flight before any is used; the score of a key is summed over its 8 lanes
+// with DPP moves; the weights are exponentiated on the fly in the P V pass.
 #define SELF_MAX_LEN 512
+#define SELF_U 4
+typedef __attribute__((ext_vector_type(4))) unsigned int self_u4;
+__device__ __forceinline__ float self_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
 __global__ __launch_bounds__(64) void attn_decoder_self_kernel(const SelfAttnArgs a) {
   __shared__ float probs[SELF_MAX_LEN];
+  __shared__ int slots[SELF_MAX_LEN];
   __shared__ float qs[64];
   const int lane = threadIdx.x;
+  const int piece = lane & 7, kg = lane >> 3;
   const int h = blockIdx.x, i = blockIdx.y;
   const int d_model = a.heads * 64;
   const int base = a.base_len[i];
   const long slot_stride = (long)a.heads * a.max_len * 64;
-  bf16_t* kown = a.k_cache + (long)i * slot_stride + (long)h * a.max_len * 64;
-  bf16_t* vown = a.v_cache + (long)i * slot_stride + (long)h * a.max_len * 64;
+  const long head_off = (long)h * a.max_len * 64;
+  bf16_t* kown = a.k_cache + (long)i * slot_stride + head_off;
+  bf16_t* vown = a.v_cache + (long)i * slot_stride + head_off;
   for (int j = 0; j < a.s_new; ++j) {
     const int p = base + j;
     if (p < a.max_len) {
@@ -177,46 +191,76 @@ __global__ __launch_bounds__(64) void attn_decoder_self_kernel(const SelfAttnArg
       vown[(long)p * 64 + lane] = row[2 * d_model + lane];
     }
   }
+  const int n_all = base + a.s_new < a.max_len ? base + a.s_new : a.max_len;
+  for (int p = lane; p < n_all; p += 64) slots[p] = p >= base ? i : a.slot_of[(long)i * a.max_len + p];
   __syncthreads();
   for (int j = 0; j < a.s_new; ++j) {
     const int n_keys = base + j + 1 < a.max_len ? base + j + 1 : a.max_len;
     qs[lane] = bf2f(a.qkv[(long)(i * a.s_new + j) * 3 * d_model + h * 64 + lane]) * 0.125f;
     __syncthreads();
+    float qr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qr[e] = qs[8 * piece + e];
     float mx = -__builtin_inff();
-    for (int p = lane; p < n_keys; p += 64) {
-      const int slot = p >= base ? i : a.slot_of[(long)i * a.max_len + p];
-      const bf16_t* kr = a.k_cache + (long)slot * slot_stride + ((long)h * a.max_len + p) * 64;
-      float s = 0.f;
+    for (int k0 = kg; k0 < n_keys; k0 += 8 * SELF_U) {
+      self_u4 u[SELF_U];
 #pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) {
-        const uint4 u = *(const uint4*)(kr + 8 * c8);
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+      for (int t = 0; t < SELF_U; ++t) {
+        const int key = k0 + 8 * t < n_keys ? k0 + 8 * t : n_keys - 1;
+        u[t] = *(const self_u4*)(a.k_cache + (long)slots[key] * slot_stride + head_off + (long)key * 64 + 8 * piece);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s += __uint_as_float(w[e] << 16) * qs[8 * c8 + 2 * e];
-          s += __uint_as_float(w[e] & 0xFFFF0000u) * qs[8 * c8 + 2 * e + 1];
+      for (int t = 0; t < SELF_U; ++t) {
+        const int key = k0 + 8 * t;
+        float sv = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sv += __uint_as_float(u[t][e] << 16) * qr[2 * e] + __uint_as_float(u[t][e] & 0xFFFF0000u) * qr[2 * e + 1];
+        sv = self_sum8(sv);
+        if (key < n_keys) {
+          mx = fmaxf(mx, sv);
+          if (piece == 0) probs[key] = sv;
         }
       }
-      probs[p] = s;
-      mx = fmaxf(mx, s);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.f;
-    for (int p = lane; p < n_keys; p += 64) {
-      const float e = __expf(probs[p] - mx);
-      probs[p] = e;
-      sum += e;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     __syncthreads();
-    float acc = 0.f;
-    for (int p = 0; p < n_keys; ++p) {
-      const int slot = p >= base ? i : a.slot_of[(long)i * a.max_len + p];
-      acc += probs[p] * bf2f(a.v_cache[(long)slot * slot_stride + ((long)h * a.max_len + p) * 64 + lane]);
+    float acc[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int k0 = kg; k0 < n_keys; k0 += 8 * SELF_U) {
+      self_u4 u[SELF_U];
+#pragma unroll
+      for (int t = 0; t < SELF_U; ++t) {
+        const int key = k0 + 8 * t < n_keys ? k0 + 8 * t : n_keys - 1;
+        u[t] = *(const self_u4*)(a.v_cache + (long)slots[key] * slot_stride + head_off + (long)key * 64 + 8 * piece);
+      }
+#pragma unroll
+      for (int t = 0; t < SELF_U; ++t) {
+        const int key = k0 + 8 * t;
+        const float pw = key < n_keys ? __expf(probs[key] - mx) : 0.f;
+        sum += pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += pw * __uint_as_float(u[t][e] << 16);
+          acc[2 * e + 1] += pw * __uint_as_float(u[t][e] & 0xFFFF0000u);
+        }
+      }
     }
-    a.out[(long)(i * a.s_new + j) * d_model + h * 64 + lane] = f2bf(acc / sum);
+    sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[e];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      acc[e] = v * inv;
+    }
+    if (kg == 0) {
+      uint4 o;
+      o.x = pack2(acc[0], acc[1]); o.y = pack2(acc[2], acc[3]);
+      o.z = pack2(acc[4], acc[5]); o.w = pack2(acc[6], acc[7]);
+      *(uint4*)(a.out + (long)(i * a.s_new + j) * d_model + h * 64 + 8 * piece) = o;
+    }
     __syncthreads();
   }
 }
