@@ -1,0 +1,10 @@
+import csv, collections, sys
+rows = csv.DictReader(open(sys.argv[1]))
+d = collections.defaultdict(list)
+for r in rows:
+    n = r['Kernel_Name']
+    d[(n[:60], r.get('Grid_Size') or r.get('Grid_Size_X'))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+tot = sum(sum(v) for v in d.values())
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[2]) if len(sys.argv) > 2 else 24]:
+    v.sort()
+    print('%-62s grid %-8s n %6d  med %7.1f us  total %7.1f ms %5.1f%%' % (k[0], k[1], len(v), v[len(v) // 2], sum(v) / 1e3, 100 * sum(v) / tot))

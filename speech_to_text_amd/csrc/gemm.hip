@@ -10,6 +10,7 @@
 // architectures/transformers/whisper_arch.py:121-136; a stride-s 'valid' Conv1D over zero-padded
 // rows is a GEMM whose A rows overlap: row stride = s * channels, K = 3 * channels).
 #include "kernels.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) float f4_t;
@@ -42,6 +43,9 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 // Blocks are renumbered so that the blocks an XCD runs (every 8th) walk neighbouring tiles and
 // share activation panels in that XCD's L2.
 // ---------------------------------------------------------------------------------------------
+#ifndef SKINNY_NT2_MIN
+#define SKINNY_NT2_MIN 0
+#endif
 #define GB_BM 128
 #define GB_BN 128
 #define GB_BK 64
@@ -186,80 +190,120 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
 // LDS and the epilogue is applied once.  blockIdx.y selects a K slice (split-K across blocks,
 // raw partial sums to slabs).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int EPI>   // MT = ceil(M / 16)
+template <int MT, int NT, int UW, int EPI>   // MT = ceil(M / 16); a block owns 16 * NT output features
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int k_per_split,
                                                           float* __restrict__ slabs) {
-  __shared__ f4_t part[3][MT][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ f4_t part[3][NT * MT][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NT);
   const int M = g.m, N = g.n, K = g.k;
-  int wn = n0 + fr; wn = wn < N ? wn : N - 1;
   const int kbeg = blockIdx.y * k_per_split;
-  const bf16_t* __restrict__ wrow = g.w + (long)wn * K + kbeg + 16 * fg;
+  const bf16_t* __restrict__ wrow[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    int wn = n0 + 16 * u + fr; wn = wn < N ? wn : N - 1;
+    wrow[u] = g.w + (long)wn * K + kbeg + 16 * fg;
+  }
   const bf16_t* __restrict__ arow[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int m = t * 16 + fr; m = m < M ? m : M - 1;
     arow[t] = g.a + (long)m * g.lda + kbeg + 16 * fg;
   }
-  f4_t acc[MT];
+  f4_t acc[NT][MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f4_t{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[u][t] = f4_t{0.f, 0.f, 0.f, 0.f};
 
   typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+  // This wave's steps are s = wave, wave + 4, ...  The layer is a latency-bound stream: all the
+  // loads of up to UW steps are issued before the first MFMA, so a K slice of 4 UW steps costs
+  // one memory round trip instead of one per step.  Steps past the end re-read the last step
+  // (no branches around the loads) and are skipped at the MFMAs.
   const int nsteps = k_per_split / 64;
-#pragma unroll 4
-  for (int s = wave; s < nsteps; s += 4) {
-    const u4_t w0 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64));
-    const u4_t w1 = __builtin_nontemporal_load((const u4_t*)(wrow + s * 64 + 8));
-    const bf8_t wf0 = __builtin_bit_cast(bf8_t, w0), wf1 = __builtin_bit_cast(bf8_t, w1);
+  const int nmy = (nsteps - wave + 3) >> 2;            // wave-uniform
+  for (int c = 0; c < nmy; c += UW) {
+    bf8_t wf[UW][NT][2], af[UW][MT][2];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64));
-      const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64 + 8));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, a0, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, a1, acc[t], 0, 0, 0);
+    for (int i = 0; i < UW; ++i) {
+      const int s = wave + 4 * (c + i < nmy ? c + i : nmy - 1);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        wf[i][u][0] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64)));
+        wf[i][u][1] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64 + 8)));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UW; ++i) {
+      const int s = wave + 4 * (c + i < nmy ? c + i : nmy - 1);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        af[i][t][0] = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64));
+        af[i][t][1] = __builtin_bit_cast(bf8_t, *(const uint4*)(arow[t] + s * 64 + 8));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UW; ++i) {
+      if (c + i < nmy) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][u][0], af[i][t][0], acc[u][t], 0, 0, 0);
+            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][u][1], af[i][t][1], acc[u][t], 0, 0, 0);
+          }
+      }
     }
   }
   if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t) part[wave - 1][t][lane] = acc[t];
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) part[wave - 1][u * MT + t][lane] = acc[u][t];
   }
   __syncthreads();
   if (wave > 0) return;
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] += part[0][t][lane] + part[1][t][lane] + part[2][t][lane];
-
-  const int n = n0 + 4 * fg;
-  if (n >= N) return;
-  const int nv = N - n < 4 ? N - n : 4;
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int m = t * 16 + fr;
-    if (m >= M) continue;
-    float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-    if (slabs) {
-      float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
-      if (nv == 4) *(float4*)o = float4{v[0], v[1], v[2], v[3]};
-      else for (int r = 0; r < nv; ++r) o[r] = v[r];
-      continue;
-    }
-    if (g.bias) for (int r = 0; r < nv; ++r) v[r] += g.bias[n + r];
-    if (EPI == EPI_GELU_BF16) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
-    const long o = (long)m * g.ldc + n;
-    if (EPI == EPI_F32) {
-      float* out = (float*)g.out;
-      for (int r = 0; r < nv; ++r) out[o + r] = v[r];
-    } else {
-      bf16_t* out = (bf16_t*)g.out;
-      if (nv == 4 && ((o & 3) == 0)) {
-        uint2 p;
-        p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *(uint2*)(out + o) = p;
+    for (int t = 0; t < MT; ++t)
+      acc[u][t] += part[0][u * MT + t][lane] + part[1][u * MT + t][lane] + part[2][u * MT + t][lane];
+
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int n = n0 + 16 * u + 4 * fg;
+    if (n >= N) continue;
+    const int nv = N - n < 4 ? N - n : 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = t * 16 + fr;
+      if (m >= M) continue;
+      float v[4] = {acc[u][t][0], acc[u][t][1], acc[u][t][2], acc[u][t][3]};
+      if (slabs) {
+        float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
+        if (nv == 4) *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+        else for (int r = 0; r < nv; ++r) o[r] = v[r];
+        continue;
+      }
+      if (g.bias) for (int r = 0; r < nv; ++r) v[r] += g.bias[n + r];
+      if (EPI == EPI_GELU_BF16) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+      const long o = (long)m * g.ldc + n;
+      if (EPI == EPI_F32) {
+        float* out = (float*)g.out;
+        for (int r = 0; r < nv; ++r) out[o + r] = v[r];
       } else {
-        for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
+        bf16_t* out = (bf16_t*)g.out;
+        if (nv == 4 && ((o & 3) == 0)) {
+          uint2 p;
+          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)(out + o) = p;
+        } else {
+          for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
+        }
       }
     }
   }
@@ -281,21 +325,43 @@ int pick_split_k(int m, int n, int k, int n_cu) {
   return best;
 }
 
-template <int MT>
-static void launch_skinny_mt(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+template <int MT, int NT, int UW>
+static void launch_skinny_uw(const GemmArgs& g, int epilogue, int split_k, float* slabs,
                              hipStream_t stream) {
-  dim3 grid((g.n + 15) / 16, split_k, 1);
+  dim3 grid((g.n + 16 * NT - 1) / (16 * NT), split_k, 1);
   const int kps = g.k / split_k;
   float* sl = split_k > 1 || epilogue < 0 ? slabs : nullptr;
   if (sl) {
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, UW, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
   } else if (epilogue == EPI_GELU_BF16) {
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_GELU_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, UW, EPI_GELU_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
   } else if (epilogue == EPI_F32) {
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, UW, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
   } else {
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, UW, EPI_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
   }
+}
+
+// UW = 1 (one step in flight per wave) is the measured optimum at 64 rows: hoisting the loads of
+// 3 or 5 steps ahead of the MFMAs costs the registers that let a second block share the CU and
+// was slower on every decoder shape of large-v3 (vocabulary projection 78 -> 94 us, FC1
+// 17.6 -> 20.1 us); the template parameter stays for smaller row counts.
+template <int MT, int NT>
+static void launch_skinny_mt(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+                             hipStream_t stream) {
+  launch_skinny_uw<MT, NT, 1>(g, epilogue, split_k, slabs, stream);
+}
+
+// Every block re-reads the whole activation matrix (from L2), so wide layers give a block
+// several 16-feature tiles to amortise that read: 64 features when that still leaves two
+// blocks per CU (the vocabulary projection), 32 when it leaves at least half a block per CU.
+template <int MT>
+static void launch_skinny_nt(const GemmArgs& g, int epilogue, int split_k, float* slabs,
+                             hipStream_t stream) {
+  const long blocks16 = (long)((g.n + 15) / 16) * split_k;
+  if (MT <= 4 && blocks16 >= 8 * 256) launch_skinny_mt<MT, (MT <= 4 ? 4 : 1)>(g, epilogue, split_k, slabs, stream);
+  else if (MT <= 8 && split_k == 1 && blocks16 >= 256 + SKINNY_NT2_MIN) launch_skinny_mt<MT, (MT <= 8 ? 2 : 1)>(g, epilogue, split_k, slabs, stream);
+  else launch_skinny_mt<MT, 1>(g, epilogue, split_k, slabs, stream);
 }
 
 // epilogue < 0: always write raw partial sums to slabs (even with split_k == 1).
@@ -303,14 +369,14 @@ void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* sla
                         hipStream_t stream) {
   const int mt = (g.m + 15) / 16;
   switch (mt) {
-    case 1: launch_skinny_mt<1>(g, epilogue, split_k, slabs, stream); break;
-    case 2: launch_skinny_mt<2>(g, epilogue, split_k, slabs, stream); break;
-    case 3: launch_skinny_mt<3>(g, epilogue, split_k, slabs, stream); break;
-    case 4: launch_skinny_mt<4>(g, epilogue, split_k, slabs, stream); break;
-    case 5: case 6: launch_skinny_mt<6>(g, epilogue, split_k, slabs, stream); break;
-    case 7: case 8: launch_skinny_mt<8>(g, epilogue, split_k, slabs, stream); break;
-    case 9: case 10: launch_skinny_mt<10>(g, epilogue, split_k, slabs, stream); break;
-    case 11: case 12: launch_skinny_mt<12>(g, epilogue, split_k, slabs, stream); break;
-    default: launch_skinny_mt<16>(g, epilogue, split_k, slabs, stream); break;
+    case 1: launch_skinny_nt<1>(g, epilogue, split_k, slabs, stream); break;
+    case 2: launch_skinny_nt<2>(g, epilogue, split_k, slabs, stream); break;
+    case 3: launch_skinny_nt<3>(g, epilogue, split_k, slabs, stream); break;
+    case 4: launch_skinny_nt<4>(g, epilogue, split_k, slabs, stream); break;
+    case 5: case 6: launch_skinny_nt<6>(g, epilogue, split_k, slabs, stream); break;
+    case 7: case 8: launch_skinny_nt<8>(g, epilogue, split_k, slabs, stream); break;
+    case 9: case 10: launch_skinny_nt<10>(g, epilogue, split_k, slabs, stream); break;
+    case 11: case 12: launch_skinny_nt<12>(g, epilogue, split_k, slabs, stream); break;
+    default: launch_skinny_nt<16>(g, epilogue, split_k, slabs, stream); break;
   }
 }
