@@ -39,7 +39,9 @@ def test_golden_fixture(stft_fns, golden_dir):
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
-@pytest.mark.parametrize("n", [1, 399, 400, 401, 559, 560, 39519, 39520, 39521, 79040 + 77, 480000])
+@pytest.mark.parametrize("n", [1, 399, 400, 401, 559, 560, 39519, 39520, 39521,
+                               39999, 40000, 40001, 40003, 40004, 40160,      # row-transfer threshold
+                               79040 + 77, 480000])
 def test_lengths_vs_oracle(stft_fns, n_mels, n):
     rng = np.random.default_rng(n)
     audio = rng.uniform(-1, 1, n).astype(np.float32)
@@ -62,3 +64,46 @@ def test_silence_and_clamp(stft_fns):
     # all-zero clip: everything sits on the floor
     z = _gpu_mel(stft_fns[80], np.zeros(4000, dtype=np.float32))
     assert np.allclose(z, (-10.0 + 4.0) / 4.0)
+
+
+def test_more_tiles_than_compute_units(stft_fns):
+    """12.3 min of audio = 300 tiles of 247 frames: every block of the persistent grid loops, the
+    interior tiles take the row transfer and both end tiles the clamped one."""
+    n = 247 * 160 * 300 + 1234
+    rng = np.random.default_rng(7)
+    audio = rng.uniform(-1, 1, n).astype(np.float32)
+    audio[5_000_000:5_200_000] = 0.0          # a silent stretch, so the clamp is active
+    got = _gpu_mel(stft_fns[80], audio)
+    ref = oracle.whisper_log_mel_torch(audio)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < TOL
+
+
+def test_one_hour_properties(stft_fns):
+    """BASELINE size (1 h, 360 000 frames).  The oracle is too slow to run whole here, so:
+    (1) away from the clip ends a frame depends only on its own 400 samples, hence a slice of the
+    clip, transformed alone with the whole clip's maximum, reproduces the same rows bit for bit;
+    (2) the result is deterministic across calls; (3) random rows agree with the oracle."""
+    import torch
+    n = 57_600_000
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    pcm = torch.rand(n, device="cuda", generator=g) * 2 - 1
+    fn = stft_fns[80]
+    a = fn(pcm)[0]
+    b = fn(pcm)[0]
+    torch.cuda.synchronize()
+    assert a.shape == (360000, 80)
+    assert torch.equal(a, b)
+    # rows [f0, f0 + 3000) from a slice that starts 20 frames earlier and ends 20 frames later
+    host = pcm.cpu().numpy()
+    rng = np.random.default_rng(3)
+    for f0 in (1000, 123_456, 356_000):
+        lo, hi = (f0 - 20) * 160, (f0 + 3020) * 160
+        piece = oracle.whisper_log_mel(host[lo:hi])
+        # the oracle clamps with the slice's own maximum; rows above both clamps must agree
+        got = a[f0:f0 + 3000].cpu().numpy()
+        ref = piece[20:3020]
+        floor = max(got.min(), ref.min())
+        mask = (got > floor + 1e-6) & (ref > floor + 1e-6)
+        assert mask.mean() > 0.99
+        assert np.abs(got - ref)[mask].max() < TOL
