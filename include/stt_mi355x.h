@@ -42,7 +42,9 @@ typedef struct stt_logmel_plan stt_logmel_plan;
  * mel_basis: [201][n_mels] floats, row-major (MelSTFT.mel_basis[0], stft.py:61-68).
  * n_mels must be 80 or 128 and the basis must have the non-zero structure of the
  * Slaney filterbank for sr=16000, n_fft=400, fmin=0, fmax=8000 (any weights);
- * anything else is STT_ERR_UNSUPPORTED.  Allocates a few KB on the current device. */
+ * anything else is STT_ERR_UNSUPPORTED.  Allocates a few KB on the current device,
+ * among them the counters the kernels of one call synchronise through: calls on one
+ * plan must not overlap (use one plan per stream). */
 int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_basis,
                            stt_logmel_plan** plan);
 void stt_logmel_plan_destroy(stt_logmel_plan* plan);

@@ -56,12 +56,6 @@ __device__ __forceinline__ float unpark(float a) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-// Ordered float max through integer atomics (works for any sign).
-__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
-  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
-  else atomicMin((unsigned int*)addr, __float_as_uint(v));
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -183,8 +177,10 @@ struct LogmelArgs {
   int n_tiles;
   const float* ct;       // constant table, LOGMEL_TABLE_LEN floats
   float* out;            // [frame_count][NMELS], row 0 = frame_begin
-  float* piece_max;      // preset to -inf
+  float* piece_max;      // written by the block that finishes last
   float* seg_min;        // [n_tiles * 4]
+  unsigned* ticket;      // plan-owned, zero between launches
+  float* blk_max;        // plan-owned, one slot per block
 };
 
 // BULK: the piece is long enough (host-checked: hi_al - origin >= (LM_ROWS + 1) * 160) for the
@@ -348,8 +344,33 @@ void logmel_main(const LogmelArgs a) {
     printf("wave %d: barrier %u  edge %u  passA %u  barrier %u  passB %u  project+log %u  dma-wait %u  stores %u\n",
            wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7]);
 #endif
+  // Piece maximum without a preset value or an extra launch: every block publishes its own
+  // maximum, takes a ticket, and the block that draws the last ticket reduces the published
+  // values and returns the ticket counter to zero for the next launch.
   run_max = wave_max(run_max);
-  if (lane == 0 && run_max > -__builtin_inff()) atomic_max_float(a.piece_max, run_max);
+  block_barrier();                          // every wave has seen its last DMA land: LDS is free
+  float* red = (float*)lds;
+  if (lane == 0) red[wave] = run_max;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __hip_atomic_store(a.blk_max + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[4] = t == gridDim.x - 1 ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (red[4] != 0.0f && wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float m = -__builtin_inff();
+    for (int i = lane; i < (int)gridDim.x; i += 64)
+      m = fmaxf(m, __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    m = wave_max(m);
+    if (lane == 0) {
+      *a.piece_max = m;
+      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // Segment s = (tile, wave) covers rows [tile*247 + 64*wave, +64) of that tile.
@@ -386,6 +407,7 @@ struct stt_logmel_plan {
   int device;
   int n_cu;
   float* d_table;
+  unsigned* d_sync;      // [0] ticket counter, [64..] one float per block; zeroed at creation
 };
 
 static const size_t kWsHeader = 256;      // piece maximum lives in the first float
@@ -451,14 +473,18 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
   p->n_cu = prop.multiProcessorCount;
   STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table, table.size() * sizeof(float)), delete p);
   STT_HIP_OR_FAIL(hipMemcpy(p->d_table, table.data(), table.size() * sizeof(float),
-                            hipMemcpyHostToDevice), (hipFree(p->d_table), delete p));
+                            hipMemcpyHostToDevice), ((void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4), ((void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMemset(p->d_sync, 0, (64 + 1024) * 4),
+                  ((void)hipFree(p->d_sync), (void)hipFree(p->d_table), delete p));
   *plan = p;
   return STT_OK;
 }
 
 void stt_logmel_plan_destroy(stt_logmel_plan* plan) {
   if (!plan) return;
-  hipFree(plan->d_table);
+  (void)hipFree(plan->d_table);
+  (void)hipFree(plan->d_sync);
   delete plan;
 }
 
@@ -509,8 +535,9 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
   a.frame_begin = frame_begin; a.frame_count = frame_count; a.n_tiles = n_tiles;
   a.ct = plan->d_table; a.out = d_mel; a.piece_max = d_piece_max;
   a.seg_min = (float*)((char*)d_workspace + kWsHeader);
-  const int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
-  hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
+  a.ticket = plan->d_sync; a.blk_max = (float*)(plan->d_sync + 64);
+  int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
+  grid = grid < 1024 ? grid : 1024;
   const bool bulk = a.hi_al - a.origin >= (long)(LM_ROWS + 1) * LM_HOP;
   if (plan->n_mels == 80) {
     if (bulk) hipLaunchKernelGGL((logmel_main<80, true>), dim3(grid), dim3(256), 0, stream, a);
