@@ -375,53 +375,75 @@ def main():
     body_a = []
     emit = body_a.append
 
-    def emit_sub(j, loader):
-        """loader(n2) -> C++ expression of the raw v2f sample pair for input n2."""
-        nodes = sub_nodes[j]
-        ins = [n for n in nodes if g.nodes[n][0] == "in"]
-        for i, n in enumerate(ins):
+    def emit_ins(j, loader):
+        """Window multiplies of sub-DFT j.  loader(n2) -> C++ expression of the raw v2f pair."""
+        for n in sub_nodes[j]:
+            if g.nodes[n][0] != "in":
+                continue
             a = g.nodes[n][1]
             n2 = (a - j) // 8
-            if LITERALS & 8:
-                emit("    const v2f t%d = %s * v2f{%s, %s};"
-                     % (n, loader(n2), _lit(HANN[2 * a]), _lit(HANN[2 * a + 1])))
-            else:
-                # the window table is stored in the order pass A consumes it (sub-DFT j, then
-                # input n2), so one sub-DFT's 50 values are a few wide scalar loads
-                pos = 2 * (25 * (a % 8) + a // 8)
-                emit("    const v2f t%d = %s * v2f{ct[OFF_WIN + %d], ct[OFF_WIN + %d]};"
-                     % (n, loader(n2), pos, pos + 1))
+            # the window table is stored in the order pass A consumes it (sub-DFT j, then
+            # input n2), so one sub-DFT's 50 values are a few wide scalar loads
+            pos = 2 * (25 * (a % 8) + a // 8)
+            emit("  const v2f t%d = %s * v2f{ct[OFF_WIN + %d], ct[OFF_WIN + %d]};"
+                 % (n, loader(n2), pos, pos + 1))
+
+    def emit_ops(j):
+        nodes = sub_nodes[j]
         for n in nodes:
             if g.nodes[n][0] != "in":
-                emit("  " + _fmt_node(g, n, OFF_FFT))
+                emit(_fmt_node(g, n, OFF_FFT))
         for n in nodes:
             if n in boundary:
                 kind, slot = boundary[n]
                 if kind == "ag":
-                    emit("    ag[%d] = park(t%d.x); ag[%d] = park(t%d.y);" % (slot, n, slot + 1, n))
+                    emit("  ag[%d] = park(t%d.x); ag[%d] = park(t%d.y);" % (slot, n, slot + 1, n))
                 else:
-                    emit("    sv[%d] = t%d;" % (slot, n))
+                    emit("  sv[%d] = t%d;" % (slot, n))
 
     def lds_off(nn):
         return (nn // 160) * (164 * 4) + (nn % 160) * 4
 
-    for item in PASS_A_ORDER:
+    def emit_loads(r):
+        item = PASS_A_ORDER[r]
+        if isinstance(item, tuple):
+            for n2 in range(25):
+                emit("  const v4f q%d_%d = *(const v4f*)(base + %d);"
+                     % (r, n2, lds_off(2 * (item[0] + 8 * n2))))
+        else:
+            for n2 in range(25):
+                emit("  const v2f q%d_%d = *(const v2f*)(base + %d);"
+                     % (r, n2, lds_off(2 * (item + 8 * n2))))
+
+    # LM_PREFETCH_A=1 issues the LDS reads of a region while the previous region's last sub-DFT
+    # is still in its butterflies (its inputs are consumed by then, so the registers are free).
+    # Measured null (166 vs 167 us per hour of audio): LDS reads and scalar loads share one
+    # counter, and the wait for the next window values drains the prefetch anyway.
+    prefetch = os.environ.get("LM_PREFETCH_A", "0") == "1"
+    emit_loads(0)
+    for r, item in enumerate(PASS_A_ORDER):
         if isinstance(item, tuple):
             jj = item[0]
-            emit("  {   // sub-DFTs %d and %d" % (jj, jj + 1))
-            for n2 in range(25):
-                emit("    const v4f q%d = *(const v4f*)(base + %d);" % (n2, lds_off(2 * (jj + 8 * n2))))
-            emit_sub(jj, lambda n2: "v2f{q%d.x, q%d.y}" % (n2, n2))
-            emit("    __builtin_amdgcn_sched_barrier(0);")
-            emit_sub(jj + 1, lambda n2: "v2f{q%d.z, q%d.w}" % (n2, n2))
+            units = [(jj, lambda n2, r=r: "v2f{q%d_%d.x, q%d_%d.y}" % (r, n2, r, n2)),
+                     (jj + 1, lambda n2, r=r: "v2f{q%d_%d.z, q%d_%d.w}" % (r, n2, r, n2))]
         else:
-            j = item
-            emit("  {   // sub-DFT %d" % j)
-            for n2 in range(25):
-                emit("    const v2f q%d = *(const v2f*)(base + %d);" % (n2, lds_off(2 * (j + 8 * n2))))
-            emit_sub(j, lambda n2: "q%d" % n2)
-        emit("  }")
-        emit("  __builtin_amdgcn_sched_barrier(0);")
+            units = [(item, lambda n2, r=r: "q%d_%d" % (r, n2))]
+        for u, (j, loader) in enumerate(units):
+            emit("  // sub-DFT %d" % j)
+            emit_ins(j, loader)
+            if u == len(units) - 1 and r + 1 < len(PASS_A_ORDER):
+                if prefetch:
+                    emit("  __builtin_amdgcn_sched_barrier(0);")
+                    emit_loads(r + 1)
+                    emit("  __builtin_amdgcn_sched_barrier(0);")
+                    emit_ops(j)
+                else:
+                    emit_ops(j)
+                    emit("  __builtin_amdgcn_sched_barrier(0);")
+                    emit_loads(r + 1)
+            else:
+                emit_ops(j)
+            emit("  __builtin_amdgcn_sched_barrier(0);")
 
     # ---- pass B: families k2 = 0..12
     body_b = []

@@ -262,6 +262,9 @@ void logmel_main(const LogmelArgs a) {
                        (LM_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
       }
     });
+#ifdef LM_TIMING
+    asm volatile("" :: "a"(mag[0]), "a"(mag[100]), "a"(mag[200]), "a"(mag[37]));
+#endif
     LM_TICK(4)
     float mel[NMELS];
     project<NMELS>(mag, ct, mel);
@@ -279,6 +282,9 @@ void logmel_main(const LogmelArgs a) {
     }
     // the DMA issued above landed long ago; waiting here, before the stores, leaves the stores
     // in flight across the loop edge (the counter cannot tell loads from stores)
+#ifdef LM_TIMING
+    asm volatile("" :: "v"(zmin), "v"(ymax));
+#endif
     LM_TICK(5)
     __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
     asm volatile("" ::: "memory");
