@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--n-mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="large-v3", help="whisper leg / workload: model size")
-    ap.add_argument("--batch", type=int, default=32, help="whisper: 30 s windows per step and GPU")
+    ap.add_argument("--batch", type=int, default=64, help="whisper: 30 s windows per step and GPU")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--whisper-steps", type=int, default=2,
                     help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
@@ -68,6 +68,12 @@ def max_over_ranks(x, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
+
+
+# HBM bytes per logmel_main launch from the rocprofv3 PMC passes of this build (FETCH_SIZE x 2,
+# the gfx950 correction, + WRITE_SIZE; profiles/r1/logmel_1h_pmc_hbm.csv).  Counters cannot be
+# read from inside this process, so only the profiled configuration has a value.
+MEASURED_HBM_BYTES = {(57_600_000, 80): 368884285}
 
 
 def bench_logmel(args, rank, world):
@@ -121,7 +127,7 @@ def bench_logmel(args, rank, world):
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "logmel_main<%d>" % args.n_mels, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel_ms": round(k_ms, 4),
+                "traffic": MEASURED_HBM_BYTES.get((n, args.n_mels)), "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes}
 
     cpu = None
@@ -175,6 +181,19 @@ def whisper_flops(dims, batch, new_tokens, prompt_len):
     cross = dims["n_text_layer"] * 2 * T * 2 * d * d
     tok = dims["n_text_layer"] * (2 * (4 * d * d + 2 * d * d + 8 * d * d) + 4 * T * d) + 2 * d * dims["n_vocab"]
     return batch * enc, batch * cross, batch * tok * (new_tokens + prompt_len - 1)
+
+
+def decode_roofline(dims, batch, ms_per_token):
+    """HBM roofline of one token step: the decoder's bf16 weights are read once per step, the
+    cross-attention K/V of every window once per step (the dominant term), self K/V ignored."""
+    d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
+    weights = (L * 14 * d * d + V * d) * 2
+    cross_kv = batch * L * 2 * 1500 * d * 2
+    achieved = (weights + cross_kv) / (ms_per_token * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "scope": "whole token step (all kernels), algorithmic bytes: decoder weights + cross K/V",
+            "algorithmic_bytes_per_step": weights + cross_kv}
 
 
 def bench_whisper(args, rank, world, steps, warmup, with_cpu):
@@ -235,6 +254,7 @@ def bench_whisper(args, rank, world, steps, warmup, with_cpu):
                              "frac": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                              "scope": "whole encoder pass + cross K/V (all kernels), algorithmic FLOPs"},
         "decode_ms_per_token": round((dt / steps * 1e3 - enc_ms) / args.new_tokens, 3),
+        "roofline_decode": decode_roofline(dims, args.batch, (dt / steps * 1e3 - enc_ms) / args.new_tokens),
         "tokens_generated_per_window": int(lens[0]),
     }
     if with_cpu and rank == 0 and world == 1:
