@@ -32,10 +32,12 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Large-M kernel: 128 x 128 x 64 block tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA tiles.
-// One 32 KB LDS stage per block, filled by LDS-DMA (16 B per lane, no staging registers), two
-// barriers per K step; the block is small enough (32 KB LDS, < 128 VGPRs) for three or four to
-// share a CU, and it is the other blocks' MFMAs that cover a block's load latency.
+// Large-M kernel: GB_BM x 128 x 64 block tile, 4 waves (2 x 2), each wave (GB_BM / 2) x 64 =
+// (GB_BM / 32) x 4 MFMA tiles (a 128-row wave tile reads 12 KB of fragments per 32 MFMAs where a
+// 64-row one reads 8 KB per 16: LDS bandwidth, not the matrix cores, bounds the smaller tile).
+// One LDS stage per block, filled by LDS-DMA (16 B per lane, no staging registers), two
+// barriers per K step; two or three blocks share a CU, and it is the other blocks' MFMAs that
+// cover a block's load latency.
 // LDS rows are 128 B (64 k values); the 16-byte piece c of row r sits at slot c ^ (r & 7), so the
 // sixteen rows a fragment read touches spread over all banks.  An LDS-DMA instruction writes
 // 1 KB = 8 whole rows in lane order (lane -> row lane / 8, slot lane % 8), so the swizzle is
@@ -46,15 +48,18 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 #ifndef SKINNY_NT2_MIN
 #define SKINNY_NT2_MIN 0
 #endif
-#define GB_BM 128
+#ifndef GB_BM
+#define GB_BM 256
+#endif
 #define GB_BN 128
+#define GB_TM (GB_BM / 32)       // MFMA row tiles per wave
 #define GB_BK 64
 
 typedef __attribute__((address_space(3))) void gb_lds_void;
 typedef const __attribute__((address_space(1))) void gb_glb_void;
 
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_big_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[(GB_BM + GB_BN) * GB_BK * 2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,51 +77,60 @@ __global__ __launch_bounds__(256, 3) void gemm_big_kernel(const GemmArgs g, int 
   const int nk = K / GB_BK;
   constexpr int kBOff = GB_BM * GB_BK * 2;
 
-  // this lane's four source rows of A and of W (DMA instruction j = wave + 4 i covers rows 8j..8j+7)
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
+  // this lane's source rows of A and of W (DMA instruction j = wave + 4 i covers rows 8j..8j+7)
+  constexpr int kADma = GB_BM / 32, kWDma = GB_BN / 32;
+  const bf16_t* a_src[kADma];
+  const bf16_t* w_src[kWDma];
   const int piece = (lane & 7) ^ (lane >> 3);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kADma; ++i) {
     const int row = 8 * (wave + 4 * i) + (lane >> 3);
     int gm = m0 + row; gm = gm < M ? gm : M - 1;
-    int gn = n0 + row; gn = gn < N ? gn : N - 1;
     a_src[i] = A + (long)gm * g.lda + piece * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < kWDma; ++i) {
+    const int row = 8 * (wave + 4 * i) + (lane >> 3);
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
     w_src[i] = W + (long)gn * K + piece * 8;
   }
 
-  f4_t acc[4][4];   // [tn][tm]
+  f4_t acc[4][GB_TM];   // [tn][tm]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < GB_TM; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kADma; ++i)
       __builtin_amdgcn_global_load_lds((gb_glb_void*)(a_src[i] + kt * GB_BK),
                                        (gb_lds_void*)(smem + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < kWDma; ++i)
       __builtin_amdgcn_global_load_lds((gb_glb_void*)(w_src[i] + kt * GB_BK),
                                        (gb_lds_void*)(smem + kBOff + (wave + 4 * i) * 1024), 16, 0, 0);
-    }
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's pieces have landed
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf8_t wf[4], af[4];
+      bf8_t wf[4], af[GB_TM];
       const int ch = ks * 4 + fg;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int rw = wn * 64 + t * 16 + fr;
         wf[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + kBOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
-        const int rm = wm * 64 + t * 16 + fr;
+      }
+#pragma unroll
+      for (int t = 0; t < GB_TM; ++t) {
+        const int rm = wm * (GB_BM / 2) + t * 16 + fr;
         af[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(smem + rm * 128 + ((ch ^ (rm & 7)) << 4)));
       }
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < GB_TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
     }
     __syncthreads();                        // everyone is done reading before the next fill
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(256, 3) void gemm_big_kernel(const GemmArgs g, int 
   // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
   const long out_base = (long)blockIdx.z * g.out_batch_stride;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm * 64 + tm * 16 + fr;
+  for (int tm = 0; tm < GB_TM; ++tm) {
+    const int m = m0 + wm * (GB_BM / 2) + tm * 16 + fr;
     if (m >= M) continue;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
