@@ -311,7 +311,17 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
     const int nq = nq_total - qc < CQ ? nq_total - qc : CQ;
     for (int e = tid; e < CQ * 64; e += 256) {
       const int qi = e >> 6, d = e & 63;
-      qs[qi][d] = qi < nq ? bf2f(a.q[(row0 + qc + qi) * d_model + h * 64 + d]) * 0.125f : 0.f;
+      float qv = 0.f;
+      if (qi < nq) {
+        const long at = (row0 + qc + qi) * d_model + h * 64 + d;
+        if (a.q_slabs) {
+          qv = a.q_bias ? a.q_bias[h * 64 + d] : 0.f;
+          for (int sl = 0; sl < a.n_q_slabs; ++sl) qv += a.q_slabs[sl * a.q_slab_stride + at];
+        } else {
+          qv = bf2f(a.q[at]);
+        }
+      }
+      qs[qi][d] = qv * 0.125f;
     }
     __syncthreads();
     float qr[CQ][8];

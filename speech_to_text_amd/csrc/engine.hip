@@ -421,9 +421,18 @@ int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last
     pend_bias = L.bo;
     launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, L.lncg, L.lncb, e->dh, nullptr,
                          rows, d, 1e-5f, 1, 0, st);
-    dense(e, e->dh, d, L.wq_c, L.bq_c, rows, d, d, EPI_BF16, e->dq, d, nullptr, st);
-    CrossAttnArgs ca{e->dq, e->cross_k[l], e->cross_v[l], e->datt, n_seq / seq_per_win, seq_per_win,
-                     s_new, H, 1500};
+    // decode steps: the query projection is split over K like the residual projections (twice
+    // the blocks of an unsplit launch) and the attention kernel sums the slabs as it loads q
+    CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[l], e->cross_v[l], e->datt,
+                     n_seq / seq_per_win, seq_per_win, s_new, H, 1500};
+    if (rows <= 256) {
+      GemmArgs gq = gemm_args(e->dh, d, L.wq_c, nullptr, nullptr, d, rows, d, d, e->cfg.gelu_tanh);
+      const int sq = pick_split_k(rows, d, d, e->n_cu);
+      launch_gemm_skinny(gq, -1, sq, e->slabs, st);
+      ca.q_slabs = e->slabs; ca.n_q_slabs = sq; ca.q_slab_stride = slab_stride; ca.q_bias = L.bq_c;
+    } else {
+      dense(e, e->dh, d, L.wq_c, L.bq_c, rows, d, d, EPI_BF16, e->dq, d, nullptr, st);
+    }
     launch_attn_decoder_cross(ca, st);
     dense(e, e->datt, d, L.wo_c, L.bo_c, rows, d, d, EPI_RESID_F32, e->dx, d, &pend, st);
     pend_bias = L.bo_c;

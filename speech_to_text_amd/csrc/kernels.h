@@ -82,7 +82,11 @@ struct SelfAttnArgs {
 void launch_attn_decoder_self(const SelfAttnArgs& a, hipStream_t stream);
 
 struct CrossAttnArgs {
-  const bf16_t* q;     // [n_seq * s_new][d]
+  const bf16_t* q;     // [n_seq * s_new][d]; ignored when q_slabs is set
+  const float* q_slabs;   // optional: the query projection as split-K partial sums [n][rows][d] ...
+  int n_q_slabs;
+  long q_slab_stride;
+  const float* q_bias;    // ... plus its bias [d]: q = sum of slabs + bias, never rounded to bf16
   const bf16_t* k;     // [n_win][h][1500][64]   (this layer)
   const bf16_t* v;
   bf16_t* out;         // [n_seq * s_new][d]
