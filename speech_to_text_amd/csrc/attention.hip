@@ -13,8 +13,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two floats -> packed bf16 (round to nearest even) in one v_cvt_pk_bf16_f32
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_t{a, b}, bf2_t));
 }
 // multiply eight packed bf16 by 1/8 (exact: a power of two)
 __device__ __forceinline__ uint4 scale8(uint4 v) {
@@ -101,11 +104,14 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // softmax in base 2: exp(s - m) = 2^((s - m) log2 e), one v_exp_f32 per score
+      const float kLog2e = 1.4426950408889634f;
       const float mnew = fmaxf(mrun[x], mx);
-      const float alpha = __expf(mrun[x] - mnew);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[x] - mnew) * kLog2e);
+      const float moff = mnew * kLog2e;
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); rs += s[r]; }
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], kLog2e, -moff)); rs += s[r]; }
       rs += __shfl_xor(rs, 32, 64);
       lrun[x] = lrun[x] * alpha + rs;
       mrun[x] = mnew;
@@ -117,10 +123,11 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(
         u.z = pack2(s[8 * s2 + 4], s[8 * s2 + 5]); u.w = pack2(s[8 * s2 + 6], s[8 * s2 + 7]);
         pf[s2] = __builtin_bit_cast(bf8_t, u);
       }
+      // the running maximum settles after a few steps: rescale only when some lane's moved
+      const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[x][dt][r] *= alpha;
+        if (rescale) o[x][dt] *= alpha;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
           o[x][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][s2], pf[s2], o[x][dt], 0, 0, 0);
