@@ -11,6 +11,7 @@
 // rows is a GEMM whose A rows overlap: row stride = s * channels, K = 3 * channels).
 #include "kernels.h"
 #include <cstdlib>
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) float f4_t;
@@ -323,6 +324,165 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode-step kernel for 64 < M <= 256 rows: a block owns 64 output features and ALL rows, so
+// the activations are read once per 64 features instead of once per 16.  Both operands go
+// through a three-stage LDS ring filled by LDS-DMA in K chunks of 64 (same 128-byte rows and
+// source-side swizzle as the large kernel); stage t + 2 is requested while stage t is being
+// multiplied, the wait is a counted vmcnt that leaves the younger stage in flight, and there
+// is one (fence-free) barrier per chunk: it publishes stage t and, because every wave has
+// finished stage t - 1 by then, frees the slot that the new request overwrites.
+// Wave w multiplies row tiles w, w + 4, ... (TM of them) by the 4 feature tiles.
+// blockIdx.y selects a K slice; with slabs != null the raw partial sums go to slabs[y][M][N].
+// ---------------------------------------------------------------------------------------------
+template <int TM, int EPI>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_per_split,
+                                                       float* __restrict__ slabs) {
+  constexpr int ROWS = 64 * TM;                       // activation rows held per stage
+  constexpr int kStage = (ROWS + 64) * 128;           // bytes
+  constexpr int kWOff = ROWS * 128;
+  constexpr int G = 2 * TM + 2;                       // DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int M = g.m, N = g.n, K = g.k;
+  const int n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.y * k_per_split;
+  const int nt = k_per_split / 64;
+
+  // DMA instruction j covers rows 8j..8j+7 of an operand: lane -> row 8j + lane / 8 and, because
+  // the LDS image is written in lane order, the source piece (lane % 8) ^ (lane / 8)
+  const int piece = (lane & 7) ^ (lane >> 3);
+  const bf16_t* a_src[2 * TM];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2 * TM; ++i) {
+    int row = 8 * (wave + 4 * i) + (lane >> 3);
+    row = row < M ? row : M - 1;
+    a_src[i] = g.a + (long)row * g.lda + kbeg + piece * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int wn = n0 + 8 * (wave + 4 * i) + (lane >> 3);
+    wn = wn < N ? wn : N - 1;
+    w_src[i] = g.w + (long)wn * K + kbeg + piece * 8;
+  }
+  auto issue = [&](int t) {
+    unsigned char* dst = smem + (t % 3) * kStage;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(a_src[i] + t * 64),
+                                       (gb_lds_void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(w_src[i] + t * 64),
+                                       (gb_lds_void*)(dst + kWOff + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+
+  f4_t acc[4][TM];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < TM; ++t) acc[u][t] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  if (nt > 1) issue(1);
+  for (int t = 0; t < nt; ++t) {
+    // vmcnt(G): everything but the youngest stage has landed; vmcnt(0) on the last chunk
+    if (t + 1 < nt) __builtin_amdgcn_s_waitcnt((G & 15) | (7 << 4) | (15 << 8) | ((G >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) issue(t + 2);
+    const unsigned char* cur = smem + (t % 3) * kStage;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ks * 4 + fg;
+      bf8_t wf[4], af[TM];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rw = u * 16 + fr;
+        wf[u] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + kWOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int rm = (wave + 4 * m) * 16 + fr;
+        af[m] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + rm * 128 + ((ch ^ (rm & 7)) << 4)));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[m], acc[u][m], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): this wave's LDS reads are done
+  }
+
+  // epilogue: lane holds C[m = 16 (wave + 4 mt) + fr][n = n0 + 16 u + 4 fg + r]
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = n0 + 16 * u + 4 * fg;
+    if (n >= N) continue;
+    const int nv = N - n < 4 ? N - n : 4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!slabs && g.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias4[r] = g.bias[n + r < N ? n + r : N - 1];
+    }
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      const int m = (wave + 4 * mt) * 16 + fr;
+      if (m >= M) continue;
+      float v[4] = {acc[u][mt][0], acc[u][mt][1], acc[u][mt][2], acc[u][mt][3]};
+      if (slabs) {
+        float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
+        if (nv == 4) *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) o[r] = v[r];
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bias4[r];
+      if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+      }
+      const long o = (long)m * g.ldc + n;
+      if (EPI == EPI_F32) {
+        float* out = (float*)g.out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nv) out[o + r] = v[r];
+      } else {
+        bf16_t* out = (bf16_t*)g.out;
+        if (nv == 4 && ((o & 3) == 0)) {
+          uint2 p;
+          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)(out + o) = p;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) out[o + r] = f2bf(v[r]);
+        }
+      }
+    }
+  }
+}
+
+template <int TM>
+static void launch_mid_tm(const GemmArgs& g, int epilogue, int split_k, float* slabs, hipStream_t stream) {
+  dim3 grid((g.n + 63) / 64, split_k, 1);
+  const int kps = g.k / split_k;
+  float* sl = split_k > 1 || epilogue < 0 ? slabs : nullptr;
+  if (sl) hipLaunchKernelGGL((gemm_mid_kernel<TM, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+  else if (epilogue == EPI_GELU_BF16) hipLaunchKernelGGL((gemm_mid_kernel<TM, EPI_GELU_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+  else if (epilogue == EPI_F32) hipLaunchKernelGGL((gemm_mid_kernel<TM, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
+  else hipLaunchKernelGGL((gemm_mid_kernel<TM, EPI_BF16>), grid, dim3(256), 0, stream, g, kps, sl);
+}
+
 // Split K across blocks only when there are too few 16-feature blocks to cover the chip, and
 // never into more than 8 slices (the consumer re-reads every slice).
 int pick_split_k(int m, int n, int k, int n_cu) {
@@ -382,6 +542,16 @@ static void launch_skinny_nt(const GemmArgs& g, int epilogue, int split_k, float
 void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,
                         hipStream_t stream) {
   const int mt = (g.m + 15) / 16;
+  static const int mid_from = getenv("STT_MI355X_MID_FROM") ? atoi(getenv("STT_MI355X_MID_FROM")) : 5;
+  if (mt >= mid_from && mt <= 16 && (g.k / split_k) % 64 == 0) {
+    const int tm = (mt + 3) / 4;
+    switch (tm) {
+      case 1: launch_mid_tm<1>(g, epilogue, split_k, slabs, stream); return;
+      case 2: launch_mid_tm<2>(g, epilogue, split_k, slabs, stream); return;
+      case 3: launch_mid_tm<3>(g, epilogue, split_k, slabs, stream); return;
+      default: launch_mid_tm<4>(g, epilogue, split_k, slabs, stream); return;
+    }
+  }
   switch (mt) {
     case 1: launch_skinny_nt<1>(g, epilogue, split_k, slabs, stream); break;
     case 2: launch_skinny_nt<2>(g, epilogue, split_k, slabs, stream); break;
