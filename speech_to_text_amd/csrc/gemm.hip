@@ -485,17 +485,33 @@ static void launch_mid_tm(const GemmArgs& g, int epilogue, int split_k, float* s
 
 // Split K across blocks only when there are too few 16-feature blocks to cover the chip, and
 // never into more than 8 slices (the consumer re-reads every slice).
+static int mid_from_tiles() {
+  static const int v = getenv("STT_MI355X_MID_FROM") ? atoi(getenv("STT_MI355X_MID_FROM")) : 4;
+  return v;
+}
+
 int pick_split_k(int m, int n, int k, int n_cu) {
-  const int col_blocks = (n + 15) / 16;
   const int steps = k / 64;
+  const int mt = (m + 15) / 16;
   int best = 1;
+  if (mt >= mid_from_tiles() && mt <= 16) {
+    // 64-feature blocks: split until about half the CUs have a block, at least 4 chunks each
+    const int col_blocks = (n + 63) / 64;
+    for (int s = 1; s <= 8 && s <= steps; ++s) {
+      if (steps % s) continue;
+      if (steps / s < 4) break;
+      best = s;
+      if (col_blocks * s * 2 >= n_cu) break;
+    }
+    return best;
+  }
+  const int col_blocks = (n + 15) / 16;
   for (int s = 1; s <= 8 && s <= steps; ++s) {
     if (steps % s) continue;
     if (steps / s < 8) break;              // at least two steps per wave
     best = s;
     if ((long)col_blocks * s >= 2L * n_cu) break;
   }
-  (void)m;
   return best;
 }
 
@@ -542,8 +558,7 @@ static void launch_skinny_nt(const GemmArgs& g, int epilogue, int split_k, float
 void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,
                         hipStream_t stream) {
   const int mt = (g.m + 15) / 16;
-  static const int mid_from = getenv("STT_MI355X_MID_FROM") ? atoi(getenv("STT_MI355X_MID_FROM")) : 5;
-  if (mt >= mid_from && mt <= 16 && (g.k / split_k) % 64 == 0) {
+  if (mt >= mid_from_tiles() && mt <= 16 && (g.k / split_k) % 64 == 0) {
     const int tm = (mt + 3) / 4;
     switch (tm) {
       case 1: launch_mid_tm<1>(g, epilogue, split_k, slabs, stream); return;
