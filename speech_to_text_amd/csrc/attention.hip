@@ -38,14 +38,16 @@ __device__ __forceinline__ uint4 scale8(uint4 v) {
 // order inside a 16-key step is (register j of half h) -> key 16 s + 8 (j >> 2) + 4 h + (j & 3);
 // V^T is read from a [64][t_pad] image with that same order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_encoder_kernel(
+#define AE_K_BYTES (32 * 128)
+#define AE_TILE_BYTES (AE_K_BYTES + 64 * 72)
+__global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
     const bf16_t* __restrict__ vt, int t_pad, bf16_t* __restrict__ out, int t, int heads) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 256 + wave * 64;
-  if (q0 >= t) return;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[2 * AE_TILE_BYTES];
+  const int q0 = blockIdx.x * 256 + wave * 64;     // waves past the end still help stage the tiles
   const int d_model = heads * 64;
   const bf16_t* qb = q + b * batch_stride + h * 64;
   const bf16_t* kb = k + b * batch_stride + h * 64;
@@ -68,21 +70,46 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(
       for (int r = 0; r < 16; ++r) o[x][dt][r] = 0.f;
   float mrun[2] = {-__builtin_inff(), -__builtin_inff()}, lrun[2] = {0.f, 0.f};
 
-  for (int key0 = 0; key0 < t; key0 += 32) {
+  // The block's four waves walk the same keys, so a 32-key tile of K ([32][64], 128-byte rows,
+  // 16-byte pieces XOR-swizzled by row) and of V^T ([64][32], rows padded to 72 bytes) is staged
+  // once per block in LDS (two buffers; the next tile's global loads are in flight during the
+  // MFMAs) instead of once per wave from L2.
+  const int tid = threadIdx.x;
+  const int k_row = tid >> 3, k_piece = tid & 7;          // K tile: 32 rows x 8 pieces
+  const int v_row = tid >> 2, v_piece = tid & 3;          // V^T tile: 64 rows x 4 pieces
+  const unsigned k_dst = k_row * 128 + ((k_piece ^ (k_row & 7)) << 4);
+  const unsigned v_dst = AE_K_BYTES + v_row * 72 + v_piece * 16;
+  uint4 k_reg, v_reg;
+  auto fetch = [&](int key0) {
+    int ki = key0 + k_row; ki = ki < t ? ki : t - 1;
+    k_reg = *(const uint4*)(kb + (long)ki * ld + 8 * k_piece);
+    v_reg = *(const uint4*)(vb + (long)v_row * t_pad + key0 + 8 * v_piece);
+  };
+  auto stash = [&](int buf) {
+    unsigned char* base = tile + buf * AE_TILE_BYTES;
+    *(uint4*)(base + k_dst) = k_reg;
+    *(uint2*)(base + v_dst) = uint2{v_reg.x, v_reg.y};
+    *(uint2*)(base + v_dst + 8) = uint2{v_reg.z, v_reg.w};
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  for (int key0 = 0, it = 0; key0 < t; key0 += 32, ++it) {
+    const bool more = key0 + 32 < t;
+    if (more) fetch(key0 + 32);
+    const unsigned char* cur = tile + (it & 1) * AE_TILE_BYTES;
     bf8_t kf[4];
-    {
-      int ki = key0 + c; ki = ki < t ? ki : t - 1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        kf[s] = __builtin_bit_cast(bf8_t, *(const uint4*)(kb + (long)ki * ld + 16 * s + 8 * hh));
-    }
+    for (int s = 0; s < 4; ++s)
+      kf[s] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + c * 128 + (((2 * s + hh) ^ (c & 7)) << 4)));
     bf8_t vf[2][2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16_t* p = vb + (long)(32 * dt + c) * t_pad + key0 + 16 * s2 + 4 * hh;
-        const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 8);
+        const unsigned char* p = cur + AE_K_BYTES + (32 * dt + c) * 72 + (16 * s2 + 4 * hh) * 2;
+        const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 16);
         vf[dt][s2] = __builtin_bit_cast(bf8_t, uint4{lo.x, lo.y, hi.x, hi.y});
       }
 #pragma unroll
@@ -133,6 +160,8 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(
           o[x][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][s2], pf[s2], o[x][dt], 0, 0, 0);
       }
     }
+    if (more) stash((it + 1) & 1);
+    __syncthreads();
   }
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
