@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--n-mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="large-v3", help="whisper leg / workload: model size")
-    ap.add_argument("--batch", type=int, default=128, help="whisper: 30 s windows per step and GPU")
+    ap.add_argument("--batch", type=int, default=256, help="whisper: 30 s windows per step and GPU")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--whisper-steps", type=int, default=2,
                     help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
