@@ -54,6 +54,9 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 #endif
 #define GB_BN 128
 #define GB_TM (GB_BM / 32)       // MFMA row tiles per wave
+#ifndef GB_GM
+#define GB_GM 8
+#endif
 #define GB_BK 64
 
 typedef __attribute__((address_space(3))) void gb_lds_void;
@@ -71,7 +74,20 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
     const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int m0 = (tile / tiles_n) * GB_BM, n0 = (tile % tiles_n) * GB_BN;
+  // Tiles are walked in groups of GB_GM row panels, row panel fastest: the ~64 tiles an XCD has
+  // in flight then form a GB_GM x 8 patch that shares both its activation panels and its weight
+  // tiles in that XCD's L2 (walking one row panel at a time shares the activations only and
+  // streams the whole weight matrix from the memory side for every panel).
+  int tm_idx, tn_idx;
+  {
+    const int tiles_m = n_tiles / tiles_n;
+    const int per_group = GB_GM * tiles_n;
+    const int grp = tile / per_group, in = tile - grp * per_group;
+    const int gm = tiles_m - grp * GB_GM < GB_GM ? tiles_m - grp * GB_GM : GB_GM;   // rows in this group
+    tn_idx = in / gm;
+    tm_idx = grp * GB_GM + (in - tn_idx * gm);
+  }
+  const int m0 = tm_idx * GB_BM, n0 = tn_idx * GB_BN;
   const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
   const bf16_t* __restrict__ W = g.w;
   const int M = g.m, N = g.n, K = g.k;
