@@ -32,6 +32,165 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
   return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }
 
+typedef __attribute__((address_space(3))) void gb_lds_void;
+typedef const __attribute__((address_space(1))) void gb_glb_void;
+#ifndef GB_BM
+#define GB_BM 256
+#endif
+#ifndef GB_GM
+#define GB_GM 8
+#endif
+#define GB_BK 64
+
+// Epilogue of the tiled kernels: the lane holds C[m = mbase + 16 tm + fr][n = nbase + 16 tn + 4 fg + r].
+template <int EPI, int TM>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
+                                             int fr, int fg) {
+  const int M = g.m, N = g.n;
+  const long out_base = (long)blockIdx.z * g.out_batch_stride;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = mbase + tm * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = nbase + tn * 16 + 4 * fg;
+      if (n >= N) continue;
+      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+      const int nv = N - n < 4 ? N - n : 4;
+      if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += g.bias[n + r];
+      }
+      if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+      }
+      const long o = out_base + (long)m * g.ldc + n;
+      if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+        bf16_t* out = (bf16_t*)g.out;
+        if (nv == 4 && ((o & 3) == 0)) {
+          uint2 p;
+          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)(out + o) = p;
+        } else {
+          for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
+        }
+      } else {
+        float* out = (float*)g.out;
+        if (EPI == EPI_GELU_POS_F32) {
+          for (int r = 0; r < nv; ++r) v[r] += g.pos[(long)m * g.pos_ld + n + r];
+        }
+        if (EPI == EPI_RESID_F32) {
+          for (int r = 0; r < nv; ++r) out[o + r] += v[r];
+        } else {
+          for (int r = 0; r < nv; ++r) out[o + r] = v[r];
+        }
+      }
+    }
+  }
+}
+
+// XCD-aware tile order shared by the tiled kernels (see gemm_big_kernel).
+__device__ __forceinline__ void big_tile_index(int n_tiles, int tiles_n, int& tm_idx, int& tn_idx) {
+  const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int tiles_m = n_tiles / tiles_n;
+  const int per_group = GB_GM * tiles_n;
+  const int grp = tile / per_group, in = tile - grp * per_group;
+  const int gm = tiles_m - grp * GB_GM < GB_GM ? tiles_m - grp * GB_GM : GB_GM;
+  tn_idx = in / gm;
+  tm_idx = grp * GB_GM + (in - tn_idx * gm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide variant for N % 256 == 0: 256 x 256 x 64 block tile, 8 waves (2 x 4) with the same
+// 128 x 64 wave tile.  The tiled kernels are bound by the L2-to-CU stream of operand tiles
+// (waves sit in s_waitcnt for half their cycles); a 256 x 256 tile moves a third fewer bytes
+// per flop than 256 x 128.  One block per CU, so the overlap
+// comes from inside the block: two 64 KB LDS stages, the DMA of K tile t + 1 is issued right
+// after the barrier that publishes tile t and is waited for at the top of the next iteration.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
+  constexpr int kStage = (256 + 256) * GB_BK * 2, kBOff = 256 * GB_BK * 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm_idx, tn_idx;
+  big_tile_index(n_tiles, tiles_n, tm_idx, tn_idx);
+  const int m0 = tm_idx * 256, n0 = tn_idx * 256;
+  const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
+  const bf16_t* __restrict__ W = g.w;
+  const int M = g.m, N = g.n, K = g.k;
+  const int nk = K / GB_BK;
+
+  // DMA instruction j = wave + 8 i covers rows 8j..8j+7 of an operand (32 instructions each)
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+  const int piece = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (wave + 8 * i) + (lane >> 3);
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
+    a_src[i] = A + (long)gm * g.lda + piece * 8;
+    w_src[i] = W + (long)gn * K + piece * 8;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* dst = smem + (kt & 1) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(a_src[i] + kt * GB_BK),
+                                       (gb_lds_void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gb_glb_void*)(w_src[i] + kt * GB_BK),
+                                       (gb_lds_void*)(dst + kBOff + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+
+  f4_t acc[4][8];   // [tn][tm]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's pieces of tile kt have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // ... everyone's have, and everyone is done with tile kt - 1
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) issue(kt + 1);
+    const unsigned char* cur = smem + (kt & 1) * kStage;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf8_t wf[4], af[8];
+      const int ch = ks * 4 + fg;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rw = wn * 64 + t * 16 + fr;
+        wf[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + kBOff + rw * 128 + ((ch ^ (rw & 7)) << 4)));
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int rm = wm * 128 + t * 16 + fr;
+        af[t] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + rm * 128 + ((ch ^ (rm & 7)) << 4)));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's reads of the stage are done
+  }
+  big_epilogue<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fg);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Large-M kernel: GB_BM x 128 x 64 block tile, 4 waves (2 x 2), each wave (GB_BM / 2) x 64 =
 // (GB_BM / 32) x 4 MFMA tiles (a 128-row wave tile reads 12 KB of fragments per 32 MFMAs where a
@@ -49,18 +208,8 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 #ifndef SKINNY_NT2_MIN
 #define SKINNY_NT2_MIN 0
 #endif
-#ifndef GB_BM
-#define GB_BM 256
-#endif
 #define GB_BN 128
 #define GB_TM (GB_BM / 32)       // MFMA row tiles per wave
-#ifndef GB_GM
-#define GB_GM 8
-#endif
-#define GB_BK 64
-
-typedef __attribute__((address_space(3))) void gb_lds_void;
-typedef const __attribute__((address_space(1))) void gb_glb_void;
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
@@ -68,25 +217,14 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware renumbering (bijective for any tile count): hardware block b runs on XCD b % 8
-  int tile;
-  {
-    const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  // Tiles are walked in groups of GB_GM row panels, row panel fastest: the ~64 tiles an XCD has
-  // in flight then form a GB_GM x 8 patch that shares both its activation panels and its weight
-  // tiles in that XCD's L2 (walking one row panel at a time shares the activations only and
-  // streams the whole weight matrix from the memory side for every panel).
+  // XCD-aware renumbering (bijective for any tile count): hardware block b runs on XCD b % 8 and
+  // takes tile b / 8 of that XCD's contiguous share.  Tiles are walked in groups of GB_GM row
+  // panels, row panel fastest: the ~64 tiles an XCD has in flight then form a GB_GM x 8 patch that
+  // shares both its activation panels and its weight tiles in that XCD's L2 (walking one row
+  // panel at a time shares the activations only and streams the whole weight matrix from the
+  // memory side for every panel).
   int tm_idx, tn_idx;
-  {
-    const int tiles_m = n_tiles / tiles_n;
-    const int per_group = GB_GM * tiles_n;
-    const int grp = tile / per_group, in = tile - grp * per_group;
-    const int gm = tiles_m - grp * GB_GM < GB_GM ? tiles_m - grp * GB_GM : GB_GM;   // rows in this group
-    tn_idx = in / gm;
-    tm_idx = grp * GB_GM + (in - tn_idx * gm);
-  }
+  big_tile_index(n_tiles, tiles_n, tm_idx, tn_idx);
   const int m0 = tm_idx * GB_BM, n0 = tn_idx * GB_BN;
   const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
   const bf16_t* __restrict__ W = g.w;
@@ -153,53 +291,24 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
     __syncthreads();                        // everyone is done reading before the next fill
   }
 
-  // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
-  const long out_base = (long)blockIdx.z * g.out_batch_stride;
-#pragma unroll
-  for (int tm = 0; tm < GB_TM; ++tm) {
-    const int m = m0 + wm * (GB_BM / 2) + tm * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = n0 + wn * 64 + tn * 16 + 4 * fg;
-      if (n >= N) continue;
-      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
-      const int nv = N - n < 4 ? N - n : 4;
-      if (g.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += g.bias[n + r];
-      }
-      if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
-      }
-      const long o = out_base + (long)m * g.ldc + n;
-      if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
-        bf16_t* out = (bf16_t*)g.out;
-        if (nv == 4 && ((o & 3) == 0)) {
-          uint2 p;
-          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *(uint2*)(out + o) = p;
-        } else {
-          for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
-        }
-      } else {
-        float* out = (float*)g.out;
-        if (EPI == EPI_GELU_POS_F32) {
-          for (int r = 0; r < nv; ++r) v[r] += g.pos[(long)m * g.pos_ld + n + r];
-        }
-        if (EPI == EPI_RESID_F32) {
-          for (int r = 0; r < nv; ++r) out[o + r] += v[r];
-        } else {
-          for (int r = 0; r < nv; ++r) out[o + r] = v[r];
-        }
-      }
-    }
-  }
+  big_epilogue<EPI, GB_TM>(g, acc, m0 + wm * (GB_BM / 2), n0 + wn * 64, fr, fg);
 }
 
 void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
+  static const bool no_wide = getenv("STT_MI355X_NO_WIDE") != nullptr;
+  if (!no_wide && g.n % 256 == 0 && g.m >= 2048) {
+    const int tiles_n = g.n / 256, tiles_m = (g.m + 255) / 256;
+    const int n_tiles = tiles_n * tiles_m;
+    dim3 grid(n_tiles, 1, g.batch > 0 ? g.batch : 1);
+    switch (epilogue) {
+      case EPI_BF16: hipLaunchKernelGGL(gemm_wide_kernel<EPI_BF16>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_BF16>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      case EPI_RESID_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESID_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_POS_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      default: hipLaunchKernelGGL(gemm_wide_kernel<EPI_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+    }
+    return;
+  }
   const int tiles_n = (g.n + GB_BN - 1) / GB_BN, tiles_m = (g.m + GB_BM - 1) / GB_BM;
   const int n_tiles = tiles_n * tiles_m;
   dim3 grid(n_tiles, 1, g.batch > 0 ? g.batch : 1);

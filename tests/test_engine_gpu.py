@@ -184,3 +184,30 @@ def test_timestamp_filter(small):
     for row in tokens:
         ts = row >= 920
         assert not (ts[:-2] & ts[1:-1] & ts[2:]).any()      # never three timestamps in a row
+
+
+def test_encoder_states_width_256():
+    """Width 256: every encoder GEMM has N % 256 == 0 and M = 4500 rows (not a multiple of the
+    256-row tile), so the 256 x 256 tile kernel and its row clamping carry the whole pass."""
+    from speech_to_text_amd.engine import WhisperEngine
+    dims = om.Dims(n_mels=80, n_audio_ctx=1500, n_audio_state=256, n_audio_head=4, n_audio_layer=2,
+                   n_vocab=1000, n_text_ctx=64, n_text_state=256, n_text_head=4, n_text_layer=1)
+    w = _bf16_round(om.random_weights(dims, seed=3))
+    engine = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=1, max_text_len=16, max_prompt_len=4)
+    oracle = om.Whisper(dims, w)
+    g = torch.Generator().manual_seed(4)
+    mel = (torch.rand(3, 3000, 80, generator=g) * 2 - 1)
+    got = engine.encode(mel, return_output=True).cpu().numpy()
+    with torch.no_grad():
+        ref = oracle.encoder(mel).numpy()
+    assert _rel_l2(got, ref) < 1e-2
+    assert np.abs(got - ref).max() < 0.05 * ref.std() * 4
+    # and the decoder on top of it: greedy tokens identical to the oracle
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    toks, lens, _ = engine.generate(prompt, max_new_tokens=8, eos_token=999, pad_token=999,
+                                    early_stopping=False)
+    with torch.no_grad():
+        refg = om.greedy(oracle, mel, torch.tensor(prompt.astype(np.int64)), max_new_tokens=8, eos=999,
+                         pad=999, early_stopping=False)
+    assert (toks[:, 0, :8] == refg["tokens"].numpy()[:, :8]).all() if toks.ndim == 3 else \
+        (toks[:, :8] == refg["tokens"].numpy()[:, :8]).all()
