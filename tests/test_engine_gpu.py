@@ -71,6 +71,37 @@ def test_decoder_logits_teacher_forced(small):
     assert _rel_l2(got, ref) < 2e-2
 
 
+@pytest.mark.parametrize("n_tokens", [1, 16, 17, 22, 43, 44])
+def test_decoder_logits_row_counts(small, n_tokens):
+    """3 sequences x n_tokens rows: 3, 48 (the last size of the 16-feature kernel), 51, 66, 129 and
+    132 rows (the 64-feature ring kernel with one, two and three row tiles per wave, with ragged
+    last tiles): every decode-GEMM variant against the oracle."""
+    dims, _, oracle, mel = small
+    engine = _long_prompt_engine(dims)
+    engine.encode(mel)
+    tokens = np.random.default_rng(n_tokens).integers(0, 1000, size=(3, n_tokens)).astype(np.int32)
+    got = engine.decoder_logits(tokens).cpu().numpy()
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        ref, _ = oracle.decoder(torch.from_numpy(tokens).long(), oracle.cross_kv(enc))
+    ref = ref.numpy()
+    assert got.shape == ref.shape
+    assert _rel_l2(got, ref) < 2e-2
+
+
+_LONG = {}
+
+
+def _long_prompt_engine(dims):
+    """Same weights as `small`, room for 3 x 48 rows in one decoder pass."""
+    if "e" not in _LONG:
+        from speech_to_text_amd.engine import WhisperEngine
+        w = _bf16_round(om.random_weights(dims, seed=0))
+        _LONG["e"] = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=1, max_text_len=60,
+                                   max_prompt_len=48)
+    return _LONG["e"]
+
+
 def _check_tokens_against_oracle(oracle, enc, prompt, tokens, eos, pad, margin=0.05, logits_filter=None):
     """Teacher-force the oracle on the GPU's tokens: at every step the GPU token must be the
     oracle's argmax, or lose to it by less than `margin` in log-probability (bf16 near-tie)."""
