@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--model", default="large-v3", help="whisper leg / workload: model size")
     ap.add_argument("--batch", type=int, default=256, help="whisper: 30 s windows per step and GPU")
     ap.add_argument("--new-tokens", type=int, default=128)
+    ap.add_argument("--replicas", type=int, default=2,
+                    help="whisper: 2 adds the pipelined two-engine measurement, 1 skips it")
     ap.add_argument("--whisper-steps", type=int, default=2,
                     help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
     return ap.parse_args()
@@ -278,8 +280,68 @@ def bench_whisper(args, rank, world, steps, warmup, with_cpu):
                                "sample": "1 window, encoder + %d greedy tokens (not %d), torch-CPU fp32 "
                                "restatement (oracle/model.py) on the same weights" % (n_tok, args.new_tokens),
                                "first_tokens_match_gpu": bool((ref["tokens"][0].numpy() == toks[0][:n_tok]).all())}
+    if args.replicas >= 2:
+        out["pipelined"] = bench_whisper_pipelined(args, dims, weights, eng, fn, pcm, prompt, world, steps)
     del eng
     return out
+
+
+def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, steps):
+    """The same step on two engines built from the same weights, each on its own host thread and
+    stream, the second one phase late: while one decodes a batch (HBM bound) the other runs the
+    log-mel and the encoder of its next batch (matrix-core bound).  Every replica does `steps`
+    steps; the time includes the unoverlapped first and last phases."""
+    import threading
+    from speech_to_text_amd.audio.stft import WhisperSTFT
+    from speech_to_text_amd.engine import WhisperEngine
+    engs = [eng0, WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
+                                max_text_len=args.new_tokens + 8, max_prompt_len=4)]
+    fns = [fn0, WhisperSTFT(n_mel_channels=dims["n_mels"])]     # a log-mel plan serves one stream
+    dev = pcm.device
+    first = threading.Event()
+    box, errors = {}, []
+
+    def one(r, signal=False):
+        mel = fns[r](pcm)[0].view(args.batch, 3000, dims["n_mels"])
+        engs[r].encode(mel)
+        if signal:
+            box["event"] = torch.cuda.Event()
+            box["event"].record()
+            first.set()
+        engs[r].generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
+                         early_stopping=False)
+
+    def worker(r, n):
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+                if r == 1:
+                    first.wait()
+                    if "event" in box:
+                        box["event"].synchronize()
+                for i in range(n):
+                    one(r, signal=(r == 0 and i == 0))
+        except BaseException as e:
+            errors.append(e)
+        finally:
+            first.set()
+
+    one(1)                                   # warm the second engine (the first one is warm)
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(r, steps)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    if errors:
+        raise errors[0]
+    return {"value": round(world * 2 * steps * args.batch * 30.0 / dt, 1), "unit": "audio-s/s",
+            "replicas": 2, "steps_per_replica": steps, "seconds": round(dt, 3),
+            "note": "two engines per GPU, encode of one batch overlapped with decode of the other"}
 
 
 def main():

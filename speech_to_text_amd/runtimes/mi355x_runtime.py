@@ -57,20 +57,22 @@ class _Engine(object):
 
     def __init__(self, dims, weights, gelu_tanh=True):
         self.dims, self.weights, self.gelu_tanh = dims, weights, gelu_tanh
-        self._built = None
-        self._cap = None
+        self._built = {}      # replica -> WhisperEngine
+        self._cap = {}        # replica -> (batch, beams, text_len, prompt_len)
 
-    def get(self, batch, beams, text_len, prompt_len):
-        cap = self._cap
+    def get(self, batch, beams, text_len, prompt_len, replica=0):
+        """Engine `replica` (0 unless a caller pipelines batches over several engines), rebuilt
+        when a call needs more capacity than it was built for."""
+        cap = self._cap.get(replica)
         if cap is None or batch > cap[0] or beams > cap[1] or text_len > cap[2] or prompt_len > cap[3]:
             new = (max(batch, cap[0] if cap else 1), max(beams, cap[1] if cap else 1),
                    max(text_len, cap[2] if cap else 2), max(prompt_len, cap[3] if cap else 1))
-            self._built = None
-            self._built = WhisperEngine(self.dims, self.weights, max_batch=new[0], max_beams=new[1],
-                                        max_text_len=new[2], max_prompt_len=new[3],
-                                        gelu_tanh=self.gelu_tanh)
-            self._cap = new
-        return self._built
+            self._built.pop(replica, None)
+            self._built[replica] = WhisperEngine(self.dims, self.weights, max_batch=new[0],
+                                                 max_beams=new[1], max_text_len=new[2],
+                                                 max_prompt_len=new[3], gelu_tanh=self.gelu_tanh)
+            self._cap[replica] = new
+        return self._built[replica]
 
 
 class MI355XRuntime(Runtime):
@@ -113,9 +115,12 @@ class MI355XRuntime(Runtime):
     def __call__(self, inputs, *, tokens=None, tokens_length=None, encoder_output_lengths=None,
                  max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
                  num_sentences=1, temperature=None, length_temperature=None, length_power=None,
-                 logits_filter=None, early_stopping=True, **_ignored):
+                 logits_filter=None, early_stopping=True, replica=0, on_encoded=None, **_ignored):
         """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
-        arguments (lang, verbose, ...) are ignored, as the reference's runtimes do."""
+        arguments (lang, verbose, ...) are ignored, as the reference's runtimes do.
+        `replica` selects one of several engines built from the same weights and `on_encoded(event)`
+        is called once the encoder pass is enqueued (the event completes when it has run): both
+        exist so that a caller can decode one batch while another engine encodes the next."""
         if isinstance(inputs, torch.Tensor):
             mel = inputs
         else:
@@ -141,9 +146,14 @@ class MI355XRuntime(Runtime):
         if max_steps < 1:
             raise ValueError('prompt of {} tokens leaves no room under max_length = {}'.format(s, max_length))
         beam = method in ('beam', 'beam_search')
-        eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s)
+        eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s,
+                              replica=replica)
         pad = self.pad_token if self.pad_token not in (-1, None) else self.eos_token
         eng.encode(mel)
+        if on_encoded is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            on_encoded(ev)
         toks, lengths, scores = eng.generate(
             tokens, method=method, num_beams=num_beams, num_sentences=num_sentences,
             max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,

@@ -250,22 +250,28 @@ class Whisper(object):
         return segments
 
     # ---- independent windows, batched (and shardable across GPUs)
-    def infer_windows(self, mel, *, lang='en', task=None, batch_size=32, shard=None, **kwargs):
+    def infer_windows(self, mel, *, lang='en', task=None, batch_size=32, shard=None, replicas=1, **kwargs):
         """Transcribes the 30 s windows of `mel` independently of each other (the mode the
         reference reaches with condition_on_previous_text = False and no timestamp seek,
         whisper.py:301-323), `batch_size` windows per engine call.  `shard = (rank, world)`
-        keeps the windows w with w % world == rank."""
+        keeps the windows w with w % world == rank.
+
+        `replicas = 2` runs the batches alternately on two engines built from the same weights,
+        each on its own host thread and stream, the second one phase late: while one engine decodes
+        a batch (bound by HBM: the cross-attention K/V) the other encodes the next (bound by the
+        matrix cores), and the two passes share the GPU.  Results are the same as with one."""
         n_frames = len(mel)
         starts = list(range(0, n_frames, self.max_input_length))
         mine = [w for w in range(len(starts)) if shard is None or w % shard[1] == shard[0]]
         prompt = np.array(self.get_inference_tokens(lang=lang, task=task), 'int32')
         kwargs.setdefault('max_length', self.max_output_length)
+        batches = [mine[i: i + batch_size] for i in range(0, len(mine), batch_size)]
         results = {}
-        for i in range(0, len(mine), batch_size):
-            ws = mine[i: i + batch_size]
+
+        def run(ws, **extra):
             batch = torch.stack([self.pad_or_trim(mel[starts[w]: starts[w] + self.max_input_length]) for w in ws])
             out = self.compiled_infer(batch, tokens=np.tile(prompt[None], [len(ws), 1]),
-                                      tokens_length=len(prompt), **kwargs)
+                                      tokens_length=len(prompt), **kwargs, **extra)
             toks = process_model_output(out)
             for w, t in zip(ws, toks):
                 while len(t) and isinstance(t[0], (list, np.ndarray)):
@@ -276,6 +282,41 @@ class Whisper(object):
                               'end': self._get_sample_time(starts[w] + seg_len),
                               'tokens': t[t < self.eos_token_idx], 'lang': lang,
                               'text': self.decode_output(t)}
+
+        if replicas < 2 or len(batches) < 2 or not isinstance(mel, torch.Tensor) or not mel.is_cuda:
+            for ws in batches:
+                run(ws)
+            return results
+
+        import threading
+        torch.cuda.synchronize(mel.device)
+        first_encoded = threading.Event()
+        box, errors = {}, []
+
+        def worker(r):
+            try:
+                with torch.cuda.device(mel.device), torch.cuda.stream(torch.cuda.Stream(mel.device)):
+                    if r == 1:
+                        first_encoded.wait()
+                        if 'event' in box:
+                            box['event'].synchronize()
+                    for i, ws in enumerate(batches[r::2]):
+                        if r == 0 and i == 0:
+                            run(ws, replica=r, on_encoded=lambda ev: (box.__setitem__('event', ev), first_encoded.set()))
+                        else:
+                            run(ws, replica=r)
+            except BaseException as e:        # surface worker failures in the caller
+                errors.append(e)
+            finally:
+                first_encoded.set()
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
         return results
 
     def infer(self, audio, *, condition_on_previous_text=True, independent_windows=False, **kwargs):

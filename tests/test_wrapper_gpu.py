@@ -64,6 +64,24 @@ def test_window_batching_is_batch_invariant(model):
         assert np.array_equal(r["tokens"], a[w]["tokens"])
 
 
+def test_two_replicas_pipelined_equal_one(model):
+    """Five windows in batches of one, alternated over two engines on two threads and streams (one
+    decodes while the other encodes): same tokens as the single-engine pass, window by window."""
+    import torch
+    rng = np.random.default_rng(11)
+    audio = rng.uniform(-1, 1, 16000 * 140).astype(np.float32)
+    mel = model.get_input(audio, pad_or_trim=False, trim_silence=False, normalize=False)
+    assert mel.shape[0] == 14000 and isinstance(mel, torch.Tensor) and mel.is_cuda
+    one = model.infer_windows(mel, lang="en", batch_size=1, max_length=16, early_stopping=False,
+                              logits_filter=NO_TIMESTAMPS)
+    for _ in range(2):
+        two = model.infer_windows(mel, lang="en", batch_size=1, max_length=16, early_stopping=False,
+                                  logits_filter=NO_TIMESTAMPS, replicas=2)
+        assert sorted(two) == sorted(one) == [0, 1, 2, 3, 4]
+        for w in one:
+            assert np.array_equal(one[w]["tokens"], two[w]["tokens"])
+
+
 def test_sequential_long_form_with_previous_text(model):
     rng = np.random.default_rng(4)
     audio = rng.uniform(-1, 1, 16000 * 65).astype(np.float32)
