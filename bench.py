@@ -86,7 +86,7 @@ def bench_logmel(args, rank, world):
     n = int(round(57_600_000 * args.hours))
     fn = WhisperSTFT(n_mel_channels=args.n_mels)
     dev = torch.device("cuda", torch.cuda.current_device())
-    # synthetic PCM generated on the host with the survey's generator, then made resident
+    # synthetic PCM uniform(-1, 1) from numpy's default_rng(rank), generated on the host, then made resident
     rng = np.random.default_rng(rank)
     pcm = torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)).to(dev)
     frames = lib.stt_logmel_num_frames(n)
