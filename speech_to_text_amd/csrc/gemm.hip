@@ -42,37 +42,56 @@ typedef const __attribute__((address_space(1))) void gb_glb_void;
 #endif
 #define GB_BK 64
 
+// two floats -> packed bf16 (round to nearest even) in one v_cvt_pk_bf16_f32
+typedef __bf16 gb_bf2 __attribute__((ext_vector_type(2)));
+typedef float gb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gb_pack2(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(gb_f2{a, b}, gb_bf2));
+}
+// tanh-form GELU with one exp2 and one reciprocal: 0.5 x (1 + tanh(u)) = x / (1 + 2^(-2 u log2 e))
+__device__ __forceinline__ float gelu_fast(float x, int tanh_form) {
+  if (tanh_form) {
+    const float t = x * (1.0f + 0.044715f * x * x) * (-2.0f * 0.7978845608028654f * 1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+  }
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+
 // Epilogue of the tiled kernels: the lane holds C[m = mbase + 16 tm + fr][n = nbase + 16 tn + 4 fg + r].
+// Everything is done on 4-wide vectors (16-byte bias / position / residual accesses, 8-byte bf16
+// stores); a ragged last column group falls back to scalars.
 template <int EPI, int TM>
 __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
                                              int fr, int fg) {
   const int M = g.m, N = g.n;
   const long out_base = (long)blockIdx.z * g.out_batch_stride;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = mbase + tm * 16 + fr;
-    if (m >= M) continue;
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = nbase + tn * 16 + 4 * fg;
+    if (n >= N) continue;
+    const int nv = N - n < 4 ? N - n : 4;
+    f4_t bias = f4_t{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+      if (nv == 4) bias = *(const f4_t*)(g.bias + n);
+      else for (int r = 0; r < nv; ++r) bias[r] = g.bias[n + r];
+    }
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = nbase + tn * 16 + 4 * fg;
-      if (n >= N) continue;
-      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
-      const int nv = N - n < 4 ? N - n : 4;
-      if (g.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += g.bias[n + r];
-      }
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = mbase + tm * 16 + fr;
+      if (m >= M) continue;
+      f4_t v = acc[tn][tm] + bias;
       if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
       }
       const long o = out_base + (long)m * g.ldc + n;
+      const bool vec = nv == 4 && ((o & 3) == 0);
       if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
         bf16_t* out = (bf16_t*)g.out;
-        if (nv == 4 && ((o & 3) == 0)) {
+        if (vec) {
           uint2 p;
-          p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          p.x = gb_pack2(v[0], v[1]);
+          p.y = gb_pack2(v[2], v[3]);
           *(uint2*)(out + o) = p;
         } else {
           for (int r = 0; r < nv; ++r) out[o + r] = f2bf(v[r]);
@@ -80,9 +99,14 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
       } else {
         float* out = (float*)g.out;
         if (EPI == EPI_GELU_POS_F32) {
-          for (int r = 0; r < nv; ++r) v[r] += g.pos[(long)m * g.pos_ld + n + r];
+          const long po = (long)m * g.pos_ld + n;
+          if (nv == 4 && ((po & 3) == 0)) v += *(const f4_t*)(g.pos + po);
+          else for (int r = 0; r < nv; ++r) v[r] += g.pos[po + r];
         }
-        if (EPI == EPI_RESID_F32) {
+        if (vec) {
+          if (EPI == EPI_RESID_F32) v += *(const f4_t*)(out + o);
+          *(f4_t*)(out + o) = v;
+        } else if (EPI == EPI_RESID_F32) {
           for (int r = 0; r < nv; ++r) out[o + r] += v[r];
         } else {
           for (int r = 0; r < nv; ++r) out[o + r] = v[r];
