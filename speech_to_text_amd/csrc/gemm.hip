@@ -116,6 +116,44 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
   }
 }
 
+// bf16 epilogue of the wide kernel through LDS: a lane's accumulators are 4 consecutive features
+// of one row, so direct stores are 8-byte pieces, 16 rows per instruction.  Each wave instead
+// parks its 128 x 64 bf16 tile in its own 16 KB of the (now idle) operand stages (16-byte pieces
+// XOR-swizzled by row) and writes it back out as whole 128-byte rows, 8 rows per instruction.  Only full
+// tiles take this path (the caller checks); `stage` is this wave's private region.
+template <int EPI>
+__device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
+                                                   int nbase, int lane, unsigned char* stage) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = nbase + tn * 16 + 4 * fg;
+    const f4_t bias = g.bias ? *(const f4_t*)(g.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      f4_t v = acc[tn][tm] + bias;
+      if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
+      }
+      uint2 p;
+      p.x = gb_pack2(v[0], v[1]);
+      p.y = gb_pack2(v[2], v[3]);
+      const int row = tm * 16 + fr, pc = tn * 2 + (fg >> 1);
+      *(uint2*)(stage + row * 128 + ((pc ^ (row & 7)) << 4) + (fg & 1) * 8) = p;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0); the region is private to the wave
+  bf16_t* out = (bf16_t*)g.out + (long)blockIdx.z * g.out_batch_stride;
+  const int piece = lane & 7, r0 = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + r0;
+    const uint4 q = *(const uint4*)(stage + row * 128 + ((piece ^ (row & 7)) << 4));
+    *(uint4*)(out + (long)(mbase + row) * g.ldc + nbase + piece * 8) = q;
+  }
+}
+
 // XCD-aware tile order shared by the tiled kernels (see gemm_big_kernel).
 __device__ __forceinline__ void big_tile_index(int n_tiles, int tiles_n, int& tm_idx, int& tn_idx) {
   const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
@@ -212,7 +250,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int ti
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's reads of the stage are done
   }
-  big_epilogue<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fg);
+  if ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16) && m0 + 256 <= M && (g.ldc & 7) == 0 &&
+      ((blockIdx.z * g.out_batch_stride) & 7) == 0) {
+    __syncthreads();                         // every wave is done with the operand stages
+    wide_epilogue_bf16<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (128 * 128));
+  } else {
+    big_epilogue<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fg);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
