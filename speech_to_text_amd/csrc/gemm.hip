@@ -154,6 +154,39 @@ __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc
   }
 }
 
+// fp32 residual epilogue of the wide kernel, same idea: the wave's 128 x 64 tile goes through its
+// 16 KB of LDS in two halves of 32 columns (128 bytes per row, pieces XOR-swizzled by row), and
+// the read-add-write of the residual stream is done on whole 128-byte rows.
+__device__ __forceinline__ void wide_epilogue_resid(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
+                                                    int nbase, int lane, unsigned char* stage) {
+  const int fr = lane & 15, fg = lane >> 4;
+  float* out = (float*)g.out + (long)blockIdx.z * g.out_batch_stride;
+  const int piece = lane & 7, r0 = lane >> 3;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int tn = half * 2 + t2;
+      const int n = nbase + tn * 16 + 4 * fg;
+      const f4_t bias = g.bias ? *(const f4_t*)(g.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tm = 0; tm < 8; ++tm) {
+        const int row = tm * 16 + fr, pc = t2 * 4 + fg;
+        *(f4_t*)(stage + row * 128 + ((pc ^ (row & 7)) << 4)) = acc[tn][tm] + bias;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); the region is private to the wave
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + r0;
+      const f4_t v = *(const f4_t*)(stage + row * 128 + ((piece ^ (row & 7)) << 4));
+      float* dst = out + (long)(mbase + row) * g.ldc + nbase + half * 32 + piece * 4;
+      *(f4_t*)dst = *(const f4_t*)dst + v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // reads done before the second half overwrites
+  }
+}
+
 // XCD-aware tile order shared by the tiled kernels (see gemm_big_kernel).
 __device__ __forceinline__ void big_tile_index(int n_tiles, int tiles_n, int& tm_idx, int& tn_idx) {
   const int b = blockIdx.x, xcd = b & 7, q = n_tiles >> 3, r = n_tiles & 7;
@@ -254,6 +287,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int ti
       ((blockIdx.z * g.out_batch_stride) & 7) == 0) {
     __syncthreads();                         // every wave is done with the operand stages
     wide_epilogue_bf16<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (128 * 128));
+  } else if (EPI == EPI_RESID_F32 && m0 + 256 <= M && (g.ldc & 3) == 0 &&
+             ((blockIdx.z * g.out_batch_stride) & 3) == 0) {
+    __syncthreads();
+    wide_epilogue_resid(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (128 * 128));
   } else {
     big_epilogue<EPI, 8>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fg);
   }
