@@ -383,10 +383,11 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
   // cross-attention K/V of every decoder layer, once per window
   for (int l = 0; l < c.n_text_layer; ++l) {
     const LayerW& L = e->dec[l];
-    launch_gemm_big(gemm_args(e->enc_out, d, L.wkv_c, L.bkv_c, e->kv_tmp, 2 * d, rows, 2 * d, d, gt),
-                    EPI_BF16, st);
-    launch_split_heads(e->kv_tmp, 2L * d, (long)T * 2 * d, batch, T, H, e->cross_k[l], st);
-    launch_split_heads(e->kv_tmp + d, 2L * d, (long)T * 2 * d, batch, T, H, e->cross_v[l], st);
+    // K | V projection written straight into the head-major images the decoder reads
+    GemmArgs gkv = gemm_args(e->enc_out, d, L.wkv_c, L.bkv_c, e->cross_k[l], 2 * d, rows, 2 * d, d, gt);
+    gkv.out2 = e->cross_v[l];
+    gkv.kv_t = T;
+    launch_gemm_big(gkv, EPI_KV_HEADS, st);
   }
   e->enc_batch = batch;
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);

@@ -84,6 +84,16 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
       }
+      if (EPI == EPI_KV_HEADS) {               // N % 128 == 0: a 4-group never straddles a head
+        const int dm = N >> 1, sel = n >= dm, nn = sel ? n - dm : n;
+        const int bi = m / g.kv_t, t = m - bi * g.kv_t;
+        bf16_t* out = (bf16_t*)(sel ? g.out2 : g.out);
+        uint2 p;
+        p.x = gb_pack2(v[0], v[1]);
+        p.y = gb_pack2(v[2], v[3]);
+        *(uint2*)(out + (((long)bi * (dm >> 6) + (nn >> 6)) * g.kv_t + t) * 64 + (nn & 63)) = p;
+        continue;
+      }
       const long o = out_base + (long)m * g.ldc + n;
       const bool vec = nv == 4 && ((o & 3) == 0);
       if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
@@ -144,8 +154,20 @@ __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc
     }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0); the region is private to the wave
-  bf16_t* out = (bf16_t*)g.out + (long)blockIdx.z * g.out_batch_stride;
   const int piece = lane & 7, r0 = lane >> 3;
+  if (EPI == EPI_KV_HEADS) {                 // the wave's 64 columns are exactly one head of K or of V
+    const int dm = g.n >> 1, sel = nbase >= dm, nn = sel ? nbase - dm : nbase;
+    bf16_t* out = (bf16_t*)(sel ? g.out2 : g.out);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + r0, m = mbase + row;
+      const int bi = m / g.kv_t, t = m - bi * g.kv_t;
+      const uint4 q = *(const uint4*)(stage + row * 128 + ((piece ^ (row & 7)) << 4));
+      *(uint4*)(out + (((long)bi * (dm >> 6) + (nn >> 6)) * g.kv_t + t) * 64 + piece * 8) = q;
+    }
+    return;
+  }
+  bf16_t* out = (bf16_t*)g.out + (long)blockIdx.z * g.out_batch_stride;
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int row = it * 8 + r0;
@@ -283,8 +305,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int ti
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's reads of the stage are done
   }
-  if ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16) && m0 + 256 <= M && (g.ldc & 7) == 0 &&
-      ((blockIdx.z * g.out_batch_stride) & 7) == 0) {
+  if ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_KV_HEADS) && m0 + 256 <= M &&
+      (g.ldc & 7) == 0 && ((blockIdx.z * g.out_batch_stride) & 7) == 0) {
     __syncthreads();                         // every wave is done with the operand stages
     wide_epilogue_bf16<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (128 * 128));
   } else if (EPI == EPI_RESID_F32 && m0 + 256 <= M && (g.ldc & 3) == 0 &&
@@ -410,6 +432,7 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
       case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_BF16>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       case EPI_RESID_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESID_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_POS_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      case EPI_KV_HEADS: hipLaunchKernelGGL(gemm_wide_kernel<EPI_KV_HEADS>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       default: hipLaunchKernelGGL(gemm_wide_kernel<EPI_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
     }
     return;
@@ -422,6 +445,7 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
     case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     case EPI_RESID_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_RESID_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_POS_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    case EPI_KV_HEADS: hipLaunchKernelGGL(gemm_big_kernel<EPI_KV_HEADS>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     default: hipLaunchKernelGGL(gemm_big_kernel<EPI_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
   }
 }

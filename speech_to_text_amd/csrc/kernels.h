@@ -14,6 +14,8 @@ enum GemmEpilogue {
   EPI_RESID_F32 = 2,   // out_f32[m][n] += acc + bias[n]
   EPI_GELU_POS_F32 = 3,// out_f32[m][n] = gelu(acc + bias[n]) + pos[m][n]     (conv2 + sinusoids)
   EPI_F32 = 4,         // out_f32[m][n] = acc (+ bias if given)
+  EPI_KV_HEADS = 5,    // bf16, head-major: row m = (b, t) with t < kv_t, column n < N/2 -> out[b][h][t][c],
+                       // n >= N/2 -> out2[b][h][t][c] with h = (n mod N/2) / 64, c = n mod 64 (cross K | V)
 };
 
 struct GemmArgs {
@@ -30,6 +32,8 @@ struct GemmArgs {
   int m, n, k;         // k % 64 == 0
   int batch;
   int gelu_tanh;       // 1 = tanh approximation (Keras default), 0 = exact erf
+  void* out2;          // EPI_KV_HEADS: the V image
+  int kv_t;            // EPI_KV_HEADS: rows per batch item (1500)
 };
 
 // Tiled MFMA GEMM for M >= a few hundred rows (encoder, prompt pass).
