@@ -50,7 +50,7 @@ struct stt_engine {
 
   // encoder buffers
   bf16_t *mel_pad = nullptr, *h1_pad = nullptr, *eh = nullptr, *eqkv = nullptr, *evt = nullptr,
-         *eatt = nullptr, *ef = nullptr, *enc_out = nullptr, *kv_tmp = nullptr;
+         *eatt = nullptr, *ef = nullptr, *enc_out = nullptr;
   float* ex = nullptr;
   std::vector<bf16_t*> cross_k, cross_v;
   int enc_batch = 0;       // windows held by the last stt_encode
@@ -298,8 +298,7 @@ int stt_engine_finalize(stt_engine* e) {
       (rc = dev_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = dev_alloc(e, &e->ex, R * d)) ||
       (rc = dev_alloc(e, &e->eh, R * d)) || (rc = dev_alloc(e, &e->eqkv, R * 3 * d)) ||
       (rc = dev_alloc(e, &e->evt, B * H * 64 * 1536)) || (rc = dev_alloc(e, &e->eatt, R * d)) ||
-      (rc = dev_alloc(e, &e->ef, R * 4 * d)) || (rc = dev_alloc(e, &e->enc_out, R * d)) ||
-      (rc = dev_alloc(e, &e->kv_tmp, R * 2 * d))) return rc;
+      (rc = dev_alloc(e, &e->ef, R * 4 * d)) || (rc = dev_alloc(e, &e->enc_out, R * d))) return rc;
   STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
   STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
   e->cross_k.resize(c.n_text_layer); e->cross_v.resize(c.n_text_layer);
