@@ -65,7 +65,7 @@ int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_sa
  * pieces (for instance on several GPUs) and share one clip-wide maximum:
  *  stage1 computes frames [frame_begin, frame_begin + frame_count) of a clip of
  *   n_total samples.  d_pcm[0] is sample number sample_origin of the clip and
- *   n_local samples are readable (sample_origin a multiple of 4); they must cover every sample those frames touch
+ *   n_local samples (at most 2e9) are readable (sample_origin a multiple of 4); they must cover every sample those frames touch
  *   inside the clip ([160*frame_begin - 200, 160*(frame_begin+frame_count-1) + 200)
  *   intersected with [0, n_total)).  Writes z = (log10(max(mel,1e-10)) + 4) / 4 to
  *   d_mel (row 0 = frame_begin) and the piece's maximum of log10(mel) to
@@ -159,7 +159,10 @@ typedef struct {
  * out_lengths: [batch][num_sentences] generated tokens without the EOS,
  * out_scores: [batch][num_sentences] summed log-probabilities
  * (InferenceOutput of generation_utils.py:293-300, 466-481).  num_sentences is 1 for
- * greedy.  Synchronises the stream before returning. */
+ * greedy.  The work is ordered after what `stream` holds at the call, runs on a stream owned
+ * by the engine (the per-token step is recorded once into a graph there and replayed) and has
+ * finished, results in the host buffers, when the call returns.  Calls on one engine must not
+ * overlap; two engines may run at the same time from two host threads. */
 int stt_generate(stt_engine* engine, const stt_generate_params* params, const int32_t* prompt,
                  int batch, int prompt_len, int32_t* out_tokens, int32_t* out_lengths,
                  float* out_scores, void* stream);
