@@ -350,8 +350,14 @@ def main():
     if args.workload == "logmel":
         line = bench_logmel(args, rank, world)
         if args.whisper_steps > 0:
-            line["whisper"] = bench_whisper(args, rank, world, args.whisper_steps, 1,
-                                            not args.no_cpu_baseline)
+            # the extra leg must never cost the headline line: report its failure instead
+            try:
+                line["whisper"] = bench_whisper(args, rank, world, args.whisper_steps, 1,
+                                                not args.no_cpu_baseline)
+            except Exception as e:          # noqa: BLE001
+                if world > 1:
+                    raise                   # ranks must not diverge around collectives
+                line["whisper"] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         w = bench_whisper(args, rank, world, args.steps, args.warmup, not args.no_cpu_baseline)
         line = dict(w, warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None)
