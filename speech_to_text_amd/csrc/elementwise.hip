@@ -190,21 +190,32 @@ void launch_pack_mel(const float* mel, int batch, int frames, int n_mels, bf16_t
   hipLaunchKernelGGL(pack_mel_kernel, dim3(240, batch), dim3(256), 0, stream, mel, frames, n_mels, out);
 }
 
-// v[b][t][h][64] -> vt[b][h][64][t_pad] through a 64 x 64 LDS tile.
+// v[b][t][h][64] -> vt[b][h][64][t_pad] through a 64 x 64 LDS tile, 16 bytes per global access:
+// a thread loads 8 features of one time step, and stores 8 time steps of one feature.
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long ld,
                                                           long batch_stride, int t, int heads,
                                                           int t_pad, bf16_t* __restrict__ vt) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ bf16_t tile[64][72];          // [time][feature], rows padded to 144 bytes
   const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 3) + 32 * i, piece = tid & 7;
     const int tt = t0 + r;
-    tile[r][tx] = tt < t ? v[b * batch_stride + (long)tt * ld + h * 64 + tx] : (bf16_t)0;
+    uint4 val = uint4{0u, 0u, 0u, 0u};
+    if (tt < t) val = *(const uint4*)(v + b * batch_stride + (long)tt * ld + h * 64 + piece * 8);
+    *(uint4*)&tile[r][piece * 8] = val;
   }
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {     // r = feature, tx = time
-    const int tt = t0 + tx;
-    if (tt < t_pad) vt[(((long)b * heads + h) * 64 + r) * t_pad + tt] = tile[tx][r];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = (tid >> 3) + 32 * i, piece = tid & 7;      // feature, 8 time steps
+    if (t0 + piece * 8 >= t_pad) continue;                   // t_pad is a multiple of 8
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w[e] = (uint32_t)tile[piece * 8 + 2 * e][f] | ((uint32_t)tile[piece * 8 + 2 * e + 1][f] << 16);
+    *(uint4*)(vt + (((long)b * heads + h) * 64 + f) * t_pad + t0 + piece * 8) = uint4{w[0], w[1], w[2], w[3]};
   }
 }
 void launch_transpose_v(const bf16_t* v, long ld, long batch_stride, int batch, int t, int heads,
