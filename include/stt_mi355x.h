@@ -136,8 +136,7 @@ typedef struct {
   int32_t max_steps;              /* new tokens at most (= max_length - prompt length) */
   int32_t eos_token, pad_token;
   int32_t early_stopping;
-  float temperature;              /* <= 0: not applied.  Sampling is not implemented: the result
-                                     is always the argmax / top-k of the scaled scores */
+  float temperature;              /* <= 0: not applied; otherwise scores are divided by it */
   int32_t has_length_temperature;
   float length_temperature;
   int32_t has_length_power;       /* beam ranking by score / (length + 1)^length_power */
@@ -152,6 +151,13 @@ typedef struct {
   int32_t timestamp_begin;
   int32_t max_initial_timestamp;
   int32_t check_every;            /* tokens between two host checks of "all finished" (0 = 8) */
+  int32_t sample;                 /* 1: the next token (greedy) / the `num_beams` candidates (beam,
+                                     with replacement) are drawn from the categorical distribution
+                                     of the processed scores, as select_next_token does whenever a
+                                     temperature is given (generation_utils.py:546-548); 0: argmax /
+                                     top-k.  The reported score is the log-probability of the
+                                     token drawn */
+  uint64_t seed;                  /* of the draws: same seed, same inputs -> same tokens */
 } stt_generate_params;
 
 /* Generation over the last encoded batch.  prompt: host [batch][prompt_len].

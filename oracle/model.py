@@ -284,11 +284,30 @@ def process_logits(scores, lengths, generated, t, temperature=None, length_tempe
     return torch.log_softmax(scores, dim=-1)
 
 
+def gumbel_noise(seed, stream, n):
+    """The random numbers of the categorical draw of generation_utils.py:546, as the HIP path
+    generates them (the reference's `keras.random.categorical` is unseeded and backend specific,
+    so only the distribution can be shared with it): element (stream << 32 | j), j < n, of the
+    SplitMix64 sequence started at `seed`, top 23 bits -> u in (0, 1), g = -log(-log u) in
+    float32.  argmax(x + g) is a draw from softmax(x)."""
+    m = (1 << 64) - 1
+    with np.errstate(over="ignore"):
+        ctr = (np.uint64(stream) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        z = (np.uint64(seed & m) + ctr * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = ((z >> np.uint64(41)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    return torch.from_numpy(-np.log(-np.log(u, dtype=np.float32), dtype=np.float32))
+
+
 def greedy(model, mel=None, prompt=None, *, enc=None, max_new_tokens=None, max_length=None,
            eos=50257, pad=50257, early_stopping=True, logits_filter=None, temperature=None,
-           length_temperature=None, return_logits=False):
+           length_temperature=None, return_logits=False, sample_seed=None):
     """generation_utils.py:171-300.  prompt [B, S] int64.  Returns dict(tokens [B, max_steps],
-    lengths [B] (EOS not counted), scores [B])."""
+    lengths [B] (EOS not counted), scores [B]).  `sample_seed` given: the token is drawn from
+    softmax(lp) (what select_next_token does when a temperature is set, :546-548) with the
+    noise of `gumbel_noise`, stream t * B + b."""
     if enc is None:
         enc = model.encoder(mel)
     cross = model.cross_kv(enc)
@@ -307,7 +326,11 @@ def greedy(model, mel=None, prompt=None, *, enc=None, max_new_tokens=None, max_l
         if return_logits:
             all_logits.append(z)
         lp = process_logits(z, lengths, generated, t, temperature, length_temperature, logits_filter)
-        tok = lp.argmax(dim=-1)
+        if sample_seed is None:
+            tok = lp.argmax(dim=-1)
+        else:
+            noise = torch.stack([gumbel_noise(sample_seed, t * b + i, lp.shape[1]) for i in range(b)])
+            tok = (lp + noise).argmax(dim=-1)
         sc = lp.gather(1, tok[:, None])[:, 0]
         tok = torch.where(finished, torch.tensor(pad), tok)
         scores = scores + torch.where(finished, torch.tensor(0.0), sc)
@@ -325,9 +348,12 @@ def greedy(model, mel=None, prompt=None, *, enc=None, max_new_tokens=None, max_l
 
 def beam_search(model, mel=None, prompt=None, *, enc=None, num_beams=5, num_sentences=1,
                 max_new_tokens=None, max_length=None, eos=50257, pad=50257, early_stopping=True,
-                logits_filter=None, length_power=None, temperature=None, length_temperature=None):
+                logits_filter=None, length_power=None, temperature=None, length_temperature=None,
+                sample_seed=None):
     """generation_utils.py:302-481, with the beam index b * num_beams + idx // V (the
-    reference omits `* num_beams`, which only matters for batch > 1)."""
+    reference omits `* num_beams`, which only matters for batch > 1).  `sample_seed` given: the
+    num_beams candidates are categorical draws with replacement over the flattened scores
+    (:382-384, 546), draw d of batch element i with the noise stream t * B * beams + i * beams + d."""
     if enc is None:
         enc = model.encoder(mel)
     b, s = prompt.shape
@@ -356,7 +382,11 @@ def beam_search(model, mel=None, prompt=None, *, enc=None, num_beams=5, num_sent
         r = r.reshape(b, nb * v)
         if t == 0:
             r = r[:, :v]
-        idx = torch.topk(r, nb, dim=1).indices.reshape(eb)
+        if sample_seed is None:
+            idx = torch.topk(r, nb, dim=1).indices.reshape(eb)
+        else:
+            idx = torch.stack([(r[i // nb] + gumbel_noise(sample_seed, t * eb + i, r.shape[1])).argmax()
+                               for i in range(eb)])
         beam = idx // v + batch_add
         tok = idx % v
         lengths, finished = lengths[beam], finished[beam]

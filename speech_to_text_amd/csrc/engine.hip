@@ -226,7 +226,10 @@ int stt_engine_create(const stt_model_config* cfg, int max_batch, int max_beams,
   e->cfg = *cfg;
   e->max_batch = max_batch; e->max_beams = max_beams; e->max_len = max_text_len;
   e->max_prompt = max_prompt_len;
-  hipGetDevice(&e->device);
+  if (hipGetDevice(&e->device) != hipSuccess) {
+    delete e;
+    return stt_fail(STT_ERR_HIP, "no current HIP device");
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) e->n_cu = prop.multiProcessorCount;
   *out = e;
@@ -550,7 +553,8 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
 
   FilterArgs f{e->d_suppress, p->n_suppress, e->d_suppress_first, p->n_suppress_first,
                p->timestamp_filter, p->timestamp_begin, p->eos_token, p->max_initial_timestamp};
-  LogitParams lp{p->temperature, p->length_temperature, p->has_length_temperature};
+  LogitParams lp{p->temperature, p->length_temperature, p->has_length_temperature,
+                 p->sample ? 1 : 0, (unsigned long long)p->seed};
   auto select = [&](int s_new) {
     if (p->method == STT_METHOD_BEAM)
       launch_beam_step(gs, f, lp, batch, beams, nsent, V, max_steps, e->max_len, s_new, p->eos_token,

@@ -95,16 +95,22 @@ __device__ RowMask prepare_row(float* __restrict__ row, int n_vocab, const Filte
   return m;
 }
 
-// max / first argmax / logsumexp of the masked row
-__device__ void row_stats(const float* __restrict__ row, RowMask m, float* sh, int* shi,
-                          float& out_max, int& out_arg, float& out_lse) {
+// Random numbers of the categorical draw (`keras.random.categorical`, generation_utils.py:546),
+// counter based so that a recorded step can be replayed: element `(stream << 32) | j` of the
+// SplitMix64 sequence started at `seed`, its top 23 bits as u = (k + 1/2) / 2^23 in (0, 1), and
+// the standard Gumbel variate -log(-log u).  argmax_j (x_j + g_j) is a draw from softmax(x).
+__device__ __forceinline__ float gumbel_noise(unsigned long long seed, unsigned stream, unsigned j) {
+  unsigned long long z = seed + (((unsigned long long)stream << 32) | j) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = ((float)(unsigned)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
+  return -logf(-logf(u));
+}
+
+// first argmax over the block of (value, index) pairs; every thread gets the result
+__device__ void block_argmax(float& mx, int& arg, float* sh, int* shi) {
   const int tid = threadIdx.x;
-  float mx = NEG_INF;
-  int arg = 0x7fffffff;
-  for (int i = m.lo + tid; i < m.hi; i += 256) {
-    const float v = row[i];
-    if (v > mx) { mx = v; arg = i; }
-  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(mx, o, 64);
@@ -117,6 +123,19 @@ __device__ void row_stats(const float* __restrict__ row, RowMask m, float* sh, i
   mx = sh[0]; arg = shi[0];
   for (int w = 1; w < 4; ++w)
     if (sh[w] > mx || (sh[w] == mx && shi[w] < arg)) { mx = sh[w]; arg = shi[w]; }
+}
+
+// max / first argmax / logsumexp of the masked row
+__device__ void row_stats(const float* __restrict__ row, RowMask m, float* sh, int* shi,
+                          float& out_max, int& out_arg, float& out_lse) {
+  const int tid = threadIdx.x;
+  float mx = NEG_INF;
+  int arg = 0x7fffffff;
+  for (int i = m.lo + tid; i < m.hi; i += 256) {
+    const float v = row[i];
+    if (v > mx) { mx = v; arg = i; }
+  }
+  block_argmax(mx, arg, sh, shi);
   float se = 0.f;
   for (int i = m.lo + tid; i < m.hi; i += 256) se += __expf(row[i] - mx);
   se = block_sum(se, sh);
@@ -135,6 +154,19 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GenState s, cons
   const RowMask m = prepare_row(row, n_vocab, f, p, s.lengths[i], s.generated + (long)i * max_steps, t, sh);
   float mx, lse; int arg;
   row_stats(row, m, sh, shi, mx, arg, lse);
+  if (p.sample) {          // a draw from softmax(row) instead of its mode
+    float key = NEG_INF;
+    int karg = 0x7fffffff;
+    const unsigned stream = (unsigned)t * gridDim.x + i;
+    for (int j = m.lo + threadIdx.x; j < m.hi; j += 256) {
+      const float v = row[j];
+      if (v == NEG_INF) continue;
+      const float k = (v - lse) + gumbel_noise(p.seed, stream, j);
+      if (k > key) { key = k; karg = j; }
+    }
+    block_argmax(key, karg, sh, shi);
+    if (karg != 0x7fffffff) { arg = karg; mx = row[karg]; }
+  }
   if (threadIdx.x == 0) {
     const int was_finished = s.finished[i];
     const int tok = was_finished ? pad : arg;
@@ -261,6 +293,37 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const GenState s, int be
   }
 }
 
+// Stage B when sampling: draw d of batch element b is one categorical sample (with replacement,
+// like `keras.random.categorical(logits, beams)`) over the same (beams * V) candidates, with
+// weights exp(value / (length + 1)^length_power).
+__global__ __launch_bounds__(256) void beam_sample_kernel(const GenState s, int beams, int n_vocab,
+                                                          float length_power, int has_length_power,
+                                                          unsigned long long seed) {
+  __shared__ float sh[4];
+  __shared__ int shi[4];
+  const int b = blockIdx.x / beams, tid = threadIdx.x;
+  const int t = *s.step;
+  const int rows = t == 0 ? 1 : beams;
+  const unsigned stream = (unsigned)t * gridDim.x + blockIdx.x;
+  float key = NEG_INF;
+  int karg = 0x7fffffff;
+  for (int r = 0; r < rows; ++r) {
+    const int seq = b * beams + r;
+    const float* row = s.logits + (long)seq * n_vocab;
+    float inv = 1.0f;
+    if (has_length_power) inv = 1.0f / powf((float)(s.lengths[seq] + 1), length_power);
+    for (int j = tid; j < n_vocab; j += 256) {
+      float v = row[j];
+      if (v == NEG_INF) continue;
+      if (has_length_power) v *= inv;
+      const float k = v + gumbel_noise(seed, stream, (unsigned)(r * n_vocab + j));
+      if (k > key) { key = k; karg = r * n_vocab + j; }
+    }
+  }
+  block_argmax(key, karg, sh, shi);
+  if (tid == 0) { s.cand_idx[blockIdx.x] = karg; s.cand_val[blockIdx.x] = key; }
+}
+
 // Stage C: rebuild every sequence from its parent beam (generation_utils.py:385-408, 658-676).
 __global__ __launch_bounds__(256) void beam_reorder_kernel(const GenState s, int beams, int n_vocab,
                                                            int max_steps, int max_len, int s_new,
@@ -318,8 +381,12 @@ void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams&
   const int n_seq = batch * beams;
   hipLaunchKernelGGL(beam_logprob_kernel, dim3(n_seq), dim3(256), 0, stream, s, f, p, n_vocab,
                      max_steps, pad);
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(batch), dim3(256), 0, stream, s, beams, n_vocab,
-                     length_power, has_length_power);
+  if (p.sample)
+    hipLaunchKernelGGL(beam_sample_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
+                       length_power, has_length_power, p.seed);
+  else
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(batch), dim3(256), 0, stream, s, beams, n_vocab,
+                       length_power, has_length_power);
   hipLaunchKernelGGL(beam_reorder_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
                      max_steps, max_len, s_new, eos, pad);
   hipLaunchKernelGGL(beam_commit_kernel, dim3(n_seq), dim3(256), 0, stream, s, max_steps, max_len,

@@ -132,6 +132,8 @@ struct LogitParams {
   float temperature;       // <= 0: unused
   float length_temperature;// 0: unused
   int has_length_temperature;
+  int sample;              // 1: draw the next token(s) from the categorical distribution
+  unsigned long long seed; // of the counter-based random numbers of the draw
 };
 
 // Per sequence: filter, log_softmax; greedy: argmax + state update.

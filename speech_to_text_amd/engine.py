@@ -1,6 +1,7 @@
 """Python handle on the native Whisper engine (stt_engine_* / stt_encode / stt_generate of
 include/stt_mi355x.h).  torch only owns the device tensors handed in and out."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -43,6 +44,7 @@ class GenerateParams(C.Structure):
         ("timestamp_filter", C.c_int32), ("suppress_first", C.POINTER(C.c_int32)),
         ("n_suppress_first", C.c_int32), ("timestamp_begin", C.c_int32),
         ("max_initial_timestamp", C.c_int32), ("check_every", C.c_int32),
+        ("sample", C.c_int32), ("seed", C.c_uint64),
     ]
 
 
@@ -129,7 +131,12 @@ class WhisperEngine(object):
 
     def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
                  eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
-                 length_power=None, logits_filter=None, check_every=8):
+                 length_power=None, logits_filter=None, check_every=8, sample=None, seed=None):
+        """`temperature` given (and not 0) means, as in the reference (generation_utils.py:538-548),
+        that tokens are drawn from the categorical distribution of the processed scores instead of
+        taking the argmax / top-k; `sample = False` keeps the rescaling but not the draw.  `seed`
+        makes the draws repeatable (default: fresh entropy per call, like the reference's
+        unseeded `keras.random.categorical`)."""
         prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
         if prompt.ndim == 1:
             prompt = prompt[None]
@@ -151,6 +158,9 @@ class WhisperEngine(object):
         p.has_length_power = 0 if length_power is None else 1
         p.length_power = float(length_power or 0.0)
         p.check_every = int(check_every)
+        p.sample = int(bool(temperature) if sample is None else bool(sample))
+        if p.sample:
+            p.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
         keep = []
         if isinstance(logits_filter, TimestampFilter):
             a, bb = logits_filter.remove_tokens, logits_filter.remove_tokens_with_space

@@ -115,9 +115,12 @@ class MI355XRuntime(Runtime):
     def __call__(self, inputs, *, tokens=None, tokens_length=None, encoder_output_lengths=None,
                  max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
                  num_sentences=1, temperature=None, length_temperature=None, length_power=None,
-                 logits_filter=None, early_stopping=True, replica=0, on_encoded=None, **_ignored):
+                 logits_filter=None, early_stopping=True, seed=None, replica=0, on_encoded=None,
+                 **_ignored):
         """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
         arguments (lang, verbose, ...) are ignored, as the reference's runtimes do.
+        A `temperature` switches token selection from argmax / top-k to categorical draws, as in
+        the reference (generation_utils.py:538-548); `seed` makes the draws repeatable.
         `replica` selects one of several engines built from the same weights and `on_encoded(event)`
         is called once the encoder pass is enqueued (the event completes when it has run): both
         exist so that a caller can decode one batch while another engine encodes the next."""
@@ -159,7 +162,7 @@ class MI355XRuntime(Runtime):
             max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
             early_stopping=early_stopping, temperature=temperature,
             length_temperature=length_temperature, length_power=length_power,
-            logits_filter=logits_filter)
+            logits_filter=logits_filter, seed=seed)
         return InferenceOutput(tokens=toks, lengths=lengths, scores=scores, logits=None, state=None,
                                attention_weights=None)
 

@@ -242,3 +242,82 @@ def test_encoder_states_width_256():
                          pad=999, early_stopping=False)
     assert (toks[:, 0, :8] == refg["tokens"].numpy()[:, :8]).all() if toks.ndim == 3 else \
         (toks[:, :8] == refg["tokens"].numpy()[:, :8]).all()
+
+
+def test_greedy_sampling(small):
+    """temperature given = categorical draws (generation_utils.py:546): with the same counter-based
+    noise the GPU token must be the oracle's argmax of log-prob + noise at every step, or lose to
+    it by less than the bf16 margin; same seed -> same tokens, other seed -> other tokens."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    kw = dict(max_new_tokens=16, eos_token=999, pad_token=999, early_stopping=False, temperature=0.7)
+    tokens, lengths, scores = engine.generate(prompt, seed=1234, **kw)
+    again, _, _ = engine.generate(prompt, seed=1234, **kw)
+    other, _, _ = engine.generate(prompt, seed=99, **kw)
+    plain, _, _ = engine.generate(prompt, **{**kw, "temperature": None})
+    assert (tokens == again).all()
+    assert (tokens != other).any() and (tokens != plain).any()
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        cross = oracle.cross_kv(enc)
+        cache, offset, inputs = None, 0, torch.from_numpy(prompt).long()
+        lengths_t = torch.full((3,), 3)
+        gen = torch.from_numpy(tokens).long()
+        total = exact = 0
+        want_score = np.zeros(3)
+        for t in range(16):
+            logits, cache = oracle.decoder(inputs, cross, cache, offset)
+            offset += inputs.shape[1]
+            lp = om.process_logits(logits[:, -1], lengths_t, gen, t, temperature=0.7)
+            for i in range(3):
+                key = lp[i] + om.gumbel_noise(1234, t * 3 + i, lp.shape[1])
+                best = int(key.argmax())
+                total += 1
+                exact += best == tokens[i, t]
+                assert float(key[best] - key[tokens[i, t]]) < 0.05, (i, t)
+                want_score[i] += float(lp[i, tokens[i, t]])
+            lengths_t = lengths_t + 1
+            inputs = gen[:, t][:, None]
+    assert exact >= total - 3
+    assert np.abs(want_score - scores).max() < 0.05 * 16
+
+
+def test_beam_sampling(small):
+    """Beam search with a temperature: the candidates of a step are categorical draws with
+    replacement over the flattened beam scores (generation_utils.py:379-384, 546).  Checked for
+    the first two steps against the oracle's scores plus the same noise."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    nb, v = 4, dims.n_vocab
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    kw = dict(method="beam", num_beams=nb, num_sentences=nb, eos_token=999, pad_token=999,
+              early_stopping=False, temperature=1.3, seed=77)
+    one, _, s1 = engine.generate(prompt, max_new_tokens=1, **kw)
+    two, _, s2 = engine.generate(prompt, max_new_tokens=2, **kw)
+    assert one.shape == (3, nb, 1) and two.shape == (3, nb, 2)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        p = torch.from_numpy(prompt).long()
+        logits, _ = oracle.decoder(p, oracle.cross_kv(enc))
+        lp0 = torch.log_softmax(logits[:, -1] / 1.3, dim=-1)
+        for b in range(3):
+            for d in range(nb):
+                key = lp0[b] + om.gumbel_noise(77, 0 * 3 * nb + b * nb + d, v)
+                assert float(key.max() - key[one[b, d, 0]]) < 0.05
+                assert abs(float(lp0[b, one[b, d, 0]]) - s1[b, d]) < 0.05
+        # second step: the parents are the first step's draws (same seed, same streams)
+        for b in range(3):
+            full = torch.cat([p[b:b + 1].repeat(nb, 1), torch.from_numpy(one[b]).long()], dim=1)
+            logits, _ = oracle.decoder(full, [(k[b:b + 1].repeat(nb, 1, 1, 1), vv[b:b + 1].repeat(nb, 1, 1, 1))
+                                              for k, vv in oracle.cross_kv(enc)])
+            lp1 = torch.log_softmax(logits[:, -1] / 1.3, dim=-1)
+            lws = (lp0[b, one[b, :, 0]][:, None] + lp1).reshape(-1)
+            for d in range(nb):
+                key = lws + om.gumbel_noise(77, 1 * 3 * nb + b * nb + d, nb * v)
+                t0, t1 = int(two[b, d, 0]), int(two[b, d, 1])
+                parents = [q for q in range(nb) if int(one[b, q, 0]) == t0]
+                assert parents, "the second-step sequence must extend one of the first-step draws"
+                got = max(float(key[q * v + t1]) for q in parents)
+                assert float(key.max()) - got < 0.05
+                assert abs(max(float(lws[q * v + t1]) for q in parents) - s2[b, d]) < 0.1

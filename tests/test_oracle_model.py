@@ -122,3 +122,24 @@ def test_timestamp_filter_rules():
     gen2 = torch.tensor([[5, 21, 0, 0]])
     c = om.timestamp_filter(torch.zeros(1, 30), gen2, 2, cfg)    # last ts, penultimate text
     assert torch.isinf(c[0, :10]).all()
+
+
+def test_gumbel_draws_follow_softmax():
+    """argmax(x + gumbel_noise) must be a draw from softmax(x) (what `keras.random.categorical`
+    returns, generation_utils.py:546): chi-square of 40 000 draws against the exact probabilities."""
+    import numpy as np
+    from oracle import model as om
+    x = torch.tensor([0.3, 1.7, -0.5, 2.2, float("-inf"), 0.0, -2.0])
+    p = torch.softmax(x, 0).numpy()
+    n = 40000
+    counts = np.zeros(len(x))
+    for s in range(n):
+        counts[int((x + om.gumbel_noise(2024, s, len(x))).argmax())] += 1
+    assert counts[4] == 0
+    keep = p > 0
+    chi2 = float((((counts - n * p) ** 2)[keep] / (n * p[keep])).sum())
+    assert chi2 < 27.9          # 5 degrees of freedom, p = 1e-4 quantile is 25.7
+    # different streams and seeds give different numbers, same arguments the same numbers
+    a, b = om.gumbel_noise(1, 2, 16), om.gumbel_noise(1, 3, 16)
+    assert not torch.equal(a, b) and torch.equal(a, om.gumbel_noise(1, 2, 16))
+    assert not torch.equal(a, om.gumbel_noise(2, 2, 16))
