@@ -142,7 +142,7 @@ class WhisperEngine(object):
             prompt = prompt[None]
         b, s = prompt.shape
         beam = method in ("beam", "beam_search")
-        if not beam and method != "greedy":
+        if not beam and method not in ("greedy", "sample"):      # generation_utils.py:826-831
             raise ValueError("unsupported inference method: {}".format(method))
         nsent = int(num_sentences) if beam else 1
         p = GenerateParams()

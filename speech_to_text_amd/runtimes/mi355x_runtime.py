@@ -17,6 +17,7 @@ synthetic weights (no checkpoint can be downloaded offline).
 """
 import collections
 import os
+import threading
 
 import numpy as np
 import torch
@@ -59,6 +60,14 @@ class _Engine(object):
         self.dims, self.weights, self.gelu_tanh = dims, weights, gelu_tanh
         self._built = {}      # replica -> WhisperEngine
         self._cap = {}        # replica -> (batch, beams, text_len, prompt_len)
+        self._locks = collections.defaultdict(threading.RLock)
+        self._guard = threading.Lock()
+
+    def lock(self, replica=0):
+        """Calls on one engine must not overlap (the reference's `Stream` may call a runtime from
+        a worker thread, utils/stream.py:161-167): every use of a replica happens under its lock."""
+        with self._guard:
+            return self._locks[replica]
 
     def get(self, batch, beams, text_len, prompt_len, replica=0):
         """Engine `replica` (0 unless a caller pipelines batches over several engines), rebuilt
@@ -149,20 +158,21 @@ class MI355XRuntime(Runtime):
         if max_steps < 1:
             raise ValueError('prompt of {} tokens leaves no room under max_length = {}'.format(s, max_length))
         beam = method in ('beam', 'beam_search')
-        eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s,
-                              replica=replica)
         pad = self.pad_token if self.pad_token not in (-1, None) else self.eos_token
-        eng.encode(mel)
-        if on_encoded is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            on_encoded(ev)
-        toks, lengths, scores = eng.generate(
-            tokens, method=method, num_beams=num_beams, num_sentences=num_sentences,
-            max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
-            early_stopping=early_stopping, temperature=temperature,
-            length_temperature=length_temperature, length_power=length_power,
-            logits_filter=logits_filter, seed=seed)
+        with self.engine.lock(replica):
+            eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s,
+                                  replica=replica)
+            eng.encode(mel)
+            if on_encoded is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                on_encoded(ev)
+            toks, lengths, scores = eng.generate(
+                tokens, method=method, num_beams=num_beams, num_sentences=num_sentences,
+                max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
+                early_stopping=early_stopping, temperature=temperature,
+                length_temperature=length_temperature, length_power=length_power,
+                logits_filter=logits_filter, seed=seed)
         return InferenceOutput(tokens=toks, lengths=lengths, scores=scores, logits=None, state=None,
                                attention_weights=None)
 
@@ -172,8 +182,9 @@ class MI355XRuntime(Runtime):
             mel = torch.from_numpy(np.ascontiguousarray(np.asarray(mel, dtype=np.float32)))
         if mel.dim() == 2:
             mel = mel[None]
-        eng = self.engine.get(max(mel.shape[0], self._max_batch), 1, 8, 4)
-        return eng.encode(mel, return_output=True)
+        with self.engine.lock():
+            eng = self.engine.get(max(mel.shape[0], self._max_batch), 1, 8, 4)
+            return eng.encode(mel, return_output=True)
 
     def decoder(self, tokens, encoder_output=None, training=False, **_):
         """Logits [B, S, V] of a teacher-forced pass over the windows last given to ``encoder``
@@ -181,6 +192,7 @@ class MI355XRuntime(Runtime):
         tokens = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens, dtype=np.int32)
         if tokens.ndim == 1:
             tokens = tokens[None]
-        eng = self.engine.get(max(tokens.shape[0], self._max_batch), 1, max(8, tokens.shape[1] + 1),
-                              max(4, tokens.shape[1]))
-        return eng.decoder_logits(tokens)
+        with self.engine.lock():
+            eng = self.engine.get(max(tokens.shape[0], self._max_batch), 1, max(8, tokens.shape[1] + 1),
+                                  max(4, tokens.shape[1]))
+            return eng.decoder_logits(tokens)

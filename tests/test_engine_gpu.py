@@ -321,3 +321,25 @@ def test_beam_sampling(small):
                 got = max(float(key[q * v + t1]) for q in parents)
                 assert float(key.max()) - got < 0.05
                 assert abs(max(float(lws[q * v + t1]) for q in parents) - s2[b, d]) < 0.1
+
+
+def test_suppress_list_matches_oracle(small):
+    """A `logits_filter` given as a list of token ids (`mask_batch_tokens`, generation_utils.py:
+    521-522): with all but a handful of columns masked, every token must be one of the survivors
+    and the oracle's argmax under the same mask."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    survivors = {7, 123, 500, 998}
+    banned = [i for i in range(dims.n_vocab) if i not in survivors]
+    tokens, _, _ = engine.generate(prompt, max_new_tokens=12, eos_token=999, pad_token=999,
+                                   early_stopping=False, logits_filter=banned)
+    assert set(tokens.reshape(-1).tolist()) <= survivors
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 999, 999, logits_filter=banned)
+    assert exact >= total - 2
+    plain, _, _ = engine.generate(prompt, method="sample", max_new_tokens=4, eos_token=999, pad_token=999,
+                                  early_stopping=False)
+    ref, _, _ = engine.generate(prompt, max_new_tokens=4, eos_token=999, pad_token=999, early_stopping=False)
+    assert (plain == ref).all()          # 'sample' without a temperature is greedy (:826-831)

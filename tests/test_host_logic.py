@@ -98,3 +98,24 @@ def test_vocabulary_ids():
     v = WhisperVocabulary()
     assert len(LANGUAGES) == 99 and v.lang_to_idx["en"] == 50259 and v.lang_to_idx["fr"] == 50265
     assert v.transcribe_token_idx == 50359 and v.timestamp_begin_idx == 50364
+
+
+def test_logits_masks():
+    """The cases of the reference's `test_logits_filtering` (tests/test_utils_text.py:258-279):
+    column lists and column ranges set to -inf, on numpy arrays and on torch tensors."""
+    import torch
+    from speech_to_text_amd.text.tokens_processing import mask_batch_tokens, mask_slice_tokens, mask_tokens
+    logits = np.random.default_rng(0).normal(size=(5, 25)).astype(np.float32)
+    keep = logits.copy()
+    for wrap, unwrap in ((lambda a: a, lambda a: a), (torch.from_numpy, lambda a: a.numpy())):
+        for i in range(0, 25, 5):
+            want = logits.copy(); want[:, i:] = -np.inf
+            assert np.array_equal(unwrap(mask_slice_tokens(wrap(logits), i, remove_after=True)), want)
+            want = logits.copy(); want[:, :i] = -np.inf
+            assert np.array_equal(unwrap(mask_slice_tokens(wrap(logits), i, remove_after=False)), want)
+            indexes = [i, 24, 1]
+            want = logits.copy(); want[:, indexes] = -np.inf
+            assert np.array_equal(unwrap(mask_batch_tokens(wrap(logits), indexes)), want)
+        want = logits.copy(); want[1, 3] = want[4, 0] = -np.inf
+        assert np.array_equal(unwrap(mask_tokens(wrap(logits), [[1, 3], [4, 0]])), want)
+    assert np.array_equal(logits, keep)

@@ -82,6 +82,36 @@ def test_two_replicas_pipelined_equal_one(model):
             assert np.array_equal(one[w]["tokens"], two[w]["tokens"])
 
 
+def test_calls_from_worker_threads_are_serialised(model):
+    """The reference's `Stream` may call a runtime from worker threads (utils/stream.py:161-167):
+    four threads calling the same runtime at once must each get the single-threaded answer."""
+    import threading
+    import torch
+    rng = np.random.default_rng(21)
+    mels = [torch.from_numpy(rng.uniform(-1, 1, (1, 3000, 80)).astype(np.float32)).cuda() for _ in range(4)]
+    prompt = np.array([model.get_inference_tokens(lang="en")], dtype=np.int32)
+    kw = dict(tokens=prompt, max_new_tokens=12, early_stopping=False, logits_filter=NO_TIMESTAMPS)
+    want = [np.asarray(model.model(m, **kw).tokens) for m in mels]
+    got, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    got[i] = np.asarray(model.model(mels[i], **kw).tokens)
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for i in range(4):
+        assert np.array_equal(got[i], want[i])
+
+
 def test_sequential_long_form_with_previous_text(model):
     rng = np.random.default_rng(4)
     audio = rng.uniform(-1, 1, 16000 * 65).astype(np.float32)
