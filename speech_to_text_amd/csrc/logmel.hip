@@ -327,11 +327,7 @@ void logmel_main(const LogmelArgs a) {
       // now mel[g + 4 j + c] = element (g + 4 (lane & 3) + c) of row qrow + j
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#ifdef LM_ABLATE_STORE
-        if (qtid + j < LM_TILE_FRAMES && qrow + j < a.frame_count && zmin == 12345.678f) {
-#else
         if (qtid + j < LM_TILE_FRAMES && qrow + j < a.frame_count) {
-#endif
           float* dst = a.out + (qrow + j) * NMELS + 4 * (lane & 3);
 #pragma unroll
           for (int g = 0; g < NMELS; g += 16)
