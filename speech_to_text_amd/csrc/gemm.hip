@@ -588,6 +588,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
 // finished stage t - 1 by then, frees the slot that the new request overwrites.
 // Wave w multiplies row tiles w, w + 4, ... (TM of them) by the 4 feature tiles.
 // blockIdx.y selects a K slice; with slabs != null the raw partial sums go to slabs[y][M][N].
+// blockIdx.z selects a group of 64 * TM rows: layers whose K cannot be split (bias / GELU
+// epilogues) and that have too few 64-feature blocks to cover the chip split their rows.
 // ---------------------------------------------------------------------------------------------
 template <int TM, int EPI>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_per_split,
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_p
   const int n0 = blockIdx.x * 64;
   const int kbeg = blockIdx.y * k_per_split;
   const int nt = k_per_split / 64;
+  const int row0 = blockIdx.z * ROWS;
 
   // DMA instruction j covers rows 8j..8j+7 of an operand: lane -> row 8j + lane / 8 and, because
   // the LDS image is written in lane order, the source piece (lane % 8) ^ (lane / 8)
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_p
   const bf16_t* w_src[2];
 #pragma unroll
   for (int i = 0; i < 2 * TM; ++i) {
-    int row = 8 * (wave + 4 * i) + (lane >> 3);
+    int row = row0 + 8 * (wave + 4 * i) + (lane >> 3);
     row = row < M ? row : M - 1;
     a_src[i] = g.a + (long)row * g.lda + kbeg + piece * 8;
   }
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_p
     __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): this wave's LDS reads are done
   }
 
-  // epilogue: lane holds C[m = 16 (wave + 4 mt) + fr][n = n0 + 16 u + 4 fg + r]
+  // epilogue: lane holds C[m = row0 + 16 (wave + 4 mt) + fr][n = n0 + 16 u + 4 fg + r]
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int n = n0 + 16 * u + 4 * fg;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_p
     }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-      const int m = (wave + 4 * mt) * 16 + fr;
+      const int m = row0 + (wave + 4 * mt) * 16 + fr;
       if (m >= M) continue;
       float v[4] = {acc[u][mt][0], acc[u][mt][1], acc[u][mt][2], acc[u][mt][3]};
       if (slabs) {
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const GemmArgs g, int k_p
 
 template <int TM>
 static void launch_mid_tm(const GemmArgs& g, int epilogue, int split_k, float* slabs, hipStream_t stream) {
-  dim3 grid((g.n + 63) / 64, split_k, 1);
+  dim3 grid((g.n + 63) / 64, split_k, (g.m + 64 * TM - 1) / (64 * TM));
   const int kps = g.k / split_k;
   float* sl = split_k > 1 || epilogue < 0 ? slabs : nullptr;
   if (sl) hipLaunchKernelGGL((gemm_mid_kernel<TM, EPI_F32>), grid, dim3(256), 0, stream, g, kps, sl);
@@ -813,7 +816,13 @@ void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* sla
                         hipStream_t stream) {
   const int mt = (g.m + 15) / 16;
   if (mt >= mid_from_tiles() && mt <= 16 && (g.k / split_k) % 64 == 0) {
-    const int tm = (mt + 3) / 4;
+    // All rows in one block (the weights are then read once) unless that leaves fewer blocks than
+    // CUs: then the rows per block are halved until the chip is covered.  At 256 rows of
+    // large-v3 this took the token step from 13.7 to 12.7 ms (QKV and FC1 had 60 and 80 blocks).
+    constexpr int kFill = 256;
+    int tm = (mt + 3) / 4;
+    const long col_blocks = (g.n + 63) / 64;
+    while (tm > 1 && col_blocks * split_k * ((mt + 4 * tm - 1) / (4 * tm)) < kFill) tm = (tm + 1) / 2;
     switch (tm) {
       case 1: launch_mid_tm<1>(g, epilogue, split_k, slabs, stream); return;
       case 2: launch_mid_tm<2>(g, epilogue, split_k, slabs, stream); return;
