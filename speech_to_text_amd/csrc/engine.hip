@@ -524,6 +524,9 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   // be the legacy default stream, which cannot be captured.
   hipStream_t user_st = st;
   if (!e->gen_stream) {
+    // default priority on purpose: with a high-priority stream here, two engines driven from two
+    // host threads (one encoding on its caller's stream while the other generates) stopped making
+    // progress on ROCm 7.2, and the gain without the hang was within noise
     STT_HIP_OR_FAIL(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking), (void)0);
     STT_HIP_OR_FAIL(hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming), (void)0);
   }
