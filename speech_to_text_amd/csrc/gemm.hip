@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Decode-step kernel for 64 < M <= 256 rows: a block owns 64 output features and ALL rows, so
-// the activations are read once per 64 features instead of once per 16.  Both operands go
+// Decode-step kernel for 32 < M <= 256 rows: a block owns 64 output features and up to 256 rows,
+// so the activations are read once per 64 features instead of once per 16.  Both operands go
 // through a three-stage LDS ring filled by LDS-DMA in K chunks of 64 (same 128-byte rows and
 // source-side swizzle as the large kernel); stage t + 2 is requested while stage t is being
 // multiplied, the wait is a counted vmcnt that leaves the younger stage in flight, and there
@@ -743,7 +743,7 @@ static void launch_mid_tm(const GemmArgs& g, int epilogue, int split_k, float* s
 // Split K across blocks only when there are too few 16-feature blocks to cover the chip, and
 // never into more than 8 slices (the consumer re-reads every slice).
 static int mid_from_tiles() {
-  static const int v = getenv("STT_MI355X_MID_FROM") ? atoi(getenv("STT_MI355X_MID_FROM")) : 4;
+  static const int v = getenv("STT_MI355X_MID_FROM") ? atoi(getenv("STT_MI355X_MID_FROM")) : 3;
   return v;
 }
 

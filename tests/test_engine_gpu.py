@@ -71,11 +71,12 @@ def test_decoder_logits_teacher_forced(small):
     assert _rel_l2(got, ref) < 2e-2
 
 
-@pytest.mark.parametrize("n_tokens", [1, 16, 17, 22, 43, 44])
+@pytest.mark.parametrize("n_tokens", [1, 10, 11, 16, 17, 22, 43, 44])
 def test_decoder_logits_row_counts(small, n_tokens):
-    """3 sequences x n_tokens rows: 3, 48 (the last size of the 16-feature kernel), 51, 66, 129 and
-    132 rows (the 64-feature ring kernel with one, two and three row tiles per wave, with ragged
-    last tiles): every decode-GEMM variant against the oracle."""
+    """3 sequences x n_tokens rows: 3 and 30 rows (the 16-feature kernel, whose last size is 32 rows),
+    33, 48, 51, 66, 129 and 132 rows (the 64-feature ring kernel with one, two and three row tiles per
+    wave, rows split over several blocks, ragged last tiles): every decode-GEMM variant against the
+    oracle."""
     dims, _, oracle, mel = small
     engine = _long_prompt_engine(dims)
     engine.encode(mel)
