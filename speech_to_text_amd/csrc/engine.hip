@@ -328,7 +328,8 @@ int stt_engine_finalize(stt_engine* e) {
       (rc = dev_alloc(e, &g.finished, S)) || (rc = dev_alloc(e, &g.next_token, S)) ||
       (rc = dev_alloc(e, &g.base_len, S)) || (rc = dev_alloc(e, &g.slot_of, S * L)) ||
       (rc = dev_alloc(e, &g.step, 64)) || (rc = dev_alloc(e, &g.cand_val, S)) ||
-      (rc = dev_alloc(e, &g.cand_idx, S)) || (rc = dev_alloc(e, &g.generated_tmp, S * L)) ||
+      (rc = dev_alloc(e, &g.cand_idx, S)) || (rc = dev_alloc(e, &g.row_val, S * 16)) ||
+      (rc = dev_alloc(e, &g.row_idx, S * 16)) || (rc = dev_alloc(e, &g.generated_tmp, S * L)) ||
       (rc = dev_alloc(e, &g.lengths_tmp, S)) || (rc = dev_alloc(e, &g.finished_tmp, S)) ||
       (rc = dev_alloc(e, &g.slot_of_tmp, S * L)) || (rc = dev_alloc(e, &g.scores_tmp, S))) return rc;
   g.all_finished = g.step + 16;

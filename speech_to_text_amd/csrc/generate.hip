@@ -30,6 +30,22 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// f(j, row[j]) for j = lo + tid, lo + tid + 256, ... < hi with eight loads in flight per thread: a
+// row is a few hundred KB read by one block, so a loop with one load per iteration is bound by
+// the latency of that load.
+template <class F>
+__device__ __forceinline__ void for_row(const float* row, int lo, int hi, F f) {
+  int j = lo + threadIdx.x;
+  for (; j + 7 * 256 < hi; j += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = row[j + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f(j + u * 256, v[u]);
+  }
+  for (; j < hi; j += 256) f(j, row[j]);
+}
+
 // Scales the row in place (temperature, length temperature), writes -inf at suppressed tokens
 // and returns the range mask of the timestamp rules.  Every thread of the block calls it.
 __device__ RowMask prepare_row(float* __restrict__ row, int n_vocab, const FilterArgs& f,
@@ -80,15 +96,14 @@ __device__ RowMask prepare_row(float* __restrict__ row, int n_vocab, const Filte
   // if the timestamps together outweigh every single text token, sample a timestamp:
   // logsumexp(logp[ts:]) > max(logp[:ts]); the log-softmax constant cancels.
   float mt = NEG_INF, ma = NEG_INF;
-  for (int i = tid; i < n_vocab; i += 256) {
-    const float v = (i < m.lo || i >= m.hi) ? NEG_INF : row[i];
+  for_row(row, m.lo, m.hi, [&](int i, float v) {
     if (i < f.timestamp_begin) mt = fmaxf(mt, v); else ma = fmaxf(ma, v);
-  }
+  });
   mt = block_max(mt, sh);
   ma = block_max(ma, sh);
   float se = 0.f;
   if (ma > NEG_INF)
-    for (int i = max(f.timestamp_begin, m.lo) + tid; i < m.hi; i += 256) se += __expf(row[i] - ma);
+    for_row(row, max(f.timestamp_begin, m.lo), m.hi, [&](int, float v) { se += __expf(v - ma); });
   se = block_sum(se, sh);
   const float ts_lse = ma > NEG_INF ? ma + __logf(se) : NEG_INF;
   if (ts_lse > mt) m.lo = max(m.lo, f.timestamp_begin);
@@ -131,13 +146,10 @@ __device__ void row_stats(const float* __restrict__ row, RowMask m, float* sh, i
   const int tid = threadIdx.x;
   float mx = NEG_INF;
   int arg = 0x7fffffff;
-  for (int i = m.lo + tid; i < m.hi; i += 256) {
-    const float v = row[i];
-    if (v > mx) { mx = v; arg = i; }
-  }
+  for_row(row, m.lo, m.hi, [&](int i, float v) { if (v > mx) { mx = v; arg = i; } });
   block_argmax(mx, arg, sh, shi);
   float se = 0.f;
-  for (int i = m.lo + tid; i < m.hi; i += 256) se += __expf(row[i] - mx);
+  for_row(row, m.lo, m.hi, [&](int, float v) { se += __expf(v - mx); });
   se = block_sum(se, sh);
   out_max = mx; out_arg = arg; out_lse = mx + __logf(se);
 }
@@ -158,12 +170,11 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GenState s, cons
     float key = NEG_INF;
     int karg = 0x7fffffff;
     const unsigned stream = (unsigned)t * gridDim.x + i;
-    for (int j = m.lo + threadIdx.x; j < m.hi; j += 256) {
-      const float v = row[j];
-      if (v == NEG_INF) continue;
+    for_row(row, m.lo, m.hi, [&](int j, float v) {
+      if (v == NEG_INF) return;
       const float k = (v - lse) + gumbel_noise(p.seed, stream, j);
       if (k > key) { key = k; karg = j; }
-    }
+    });
     block_argmax(key, karg, sh, shi);
     if (karg != 0x7fffffff) { arg = karg; mx = row[karg]; }
   }
@@ -212,13 +223,16 @@ void launch_greedy_step(const GenState& s, const FilterArgs& f, const LogitParam
 // ---------------------------------------------------------------------------------------------
 // beam search
 // ---------------------------------------------------------------------------------------------
-// Stage A: row <- running score + (finished ? {pad: 0, else -inf} : log_softmax(filtered row)).
+// Stage A: row <- running score + (finished ? {pad: 0, else -inf} : log_softmax(filtered row)),
+// and the `beams` best entries of the row (ties to the lowest token id), which is all the
+// per-window selection needs: within a row the length penalty is one positive factor.
+#define BEAM_MAX 16
 __global__ __launch_bounds__(256) void beam_logprob_kernel(const GenState s, const FilterArgs f,
                                                            const LogitParams p, int n_vocab,
-                                                           int max_steps, int pad) {
+                                                           int max_steps, int pad, int beams) {
   __shared__ float sh[4];
   __shared__ int shi[4];
-  const int i = blockIdx.x;
+  const int i = blockIdx.x, tid = threadIdx.x;
   const int t = *s.step;
   float* row = s.logits + (long)i * n_vocab;
   const RowMask m = prepare_row(row, n_vocab, f, p, s.lengths[i], s.generated + (long)i * max_steps, t, sh);
@@ -226,70 +240,69 @@ __global__ __launch_bounds__(256) void beam_logprob_kernel(const GenState s, con
   row_stats(row, m, sh, shi, mx, arg, lse);
   const float base = s.scores[i];
   const bool fin = s.finished[i];
-  for (int j = threadIdx.x; j < n_vocab; j += 256) {
+  for_row(row, 0, n_vocab, [&](int j, float x) {
     float v;
     if (fin) v = j == pad ? 0.f : NEG_INF;
-    else v = (j < m.lo || j >= m.hi) ? NEG_INF : row[j] - lse;
+    else v = (j < m.lo || j >= m.hi) ? NEG_INF : x - lse;
     row[j] = base + v;
+  });
+  if (p.sample) return;                 // the draw reads the whole rows
+  // `beams` passes of "best entry after the previous winner" in the order (value descending,
+  // token id ascending); a thread re-reads only the entries it wrote itself
+  float prev_v = __builtin_inff();
+  int prev_i = -1;
+  for (int sel = 0; sel < beams; ++sel) {
+    float bm = NEG_INF; int ba = 0x7fffffff;
+    for_row(row, 0, n_vocab, [&](int j, float v) {
+      const bool after = v < prev_v || (v == prev_v && j > prev_i);
+      if (after && v > bm) { bm = v; ba = j; }
+    });
+    block_argmax(bm, ba, sh, shi);
+    if (tid == 0) { s.row_val[i * BEAM_MAX + sel] = bm; s.row_idx[i * BEAM_MAX + sel] = ba; }
+    prev_v = bm; prev_i = ba;
+    if (ba == 0x7fffffff) prev_v = NEG_INF;     // nothing finite is left: the remaining slots stay empty
   }
 }
 
-// Stage B: per batch element, the `beams` best of (beams * V) candidates (first step: V),
-// ranked by value / (length + 1)^length_power, ties to the lowest flat index.
-#define BEAM_MAX 16
-__global__ __launch_bounds__(256) void beam_topk_kernel(const GenState s, int beams, int n_vocab,
-                                                        float length_power, int has_length_power) {
-  __shared__ float cv[256 * BEAM_MAX];
-  __shared__ int ci[256 * BEAM_MAX];
-  __shared__ float sh[4];
-  __shared__ int shi[4];
-  __shared__ int shpos[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// Stage B: per batch element, the `beams` best of the rows' candidates (first step: the first
+// row only), ranked by value / (length + 1)^length_power, ties to the lowest flat index
+// row * V + token.  One wave per batch element.
+__global__ __launch_bounds__(64) void beam_topk_kernel(const GenState s, int beams, int n_vocab,
+                                                       float length_power, int has_length_power) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int t = *s.step;
   const int rows = t == 0 ? 1 : beams;
-  float lv[BEAM_MAX]; int li[BEAM_MAX];
+  // lane -> candidates lane, lane + 64, ... of the rows * beams (<= 256)
+  float cvv[4]; int cii[4];
 #pragma unroll
-  for (int k = 0; k < BEAM_MAX; ++k) { lv[k] = NEG_INF; li[k] = 0x7fffffff; }
-  for (int r = 0; r < rows; ++r) {
-    const int seq = b * beams + r;
-    const float* row = s.logits + (long)seq * n_vocab;
-    float inv = 1.0f;
-    if (has_length_power) inv = 1.0f / powf((float)(s.lengths[seq] + 1), length_power);
-    for (int j = tid; j < n_vocab; j += 256) {
-      const float v = has_length_power ? row[j] * inv : row[j];
-      if (v > lv[beams - 1]) {          // insert (indices arrive in increasing order per thread)
-        int k = beams - 1;
-        while (k > 0 && v > lv[k - 1]) { lv[k] = lv[k - 1]; li[k] = li[k - 1]; --k; }
-        lv[k] = v; li[k] = r * n_vocab + j;
+  for (int q = 0; q < 4; ++q) {
+    const int c = lane + 64 * q;
+    cvv[q] = NEG_INF; cii[q] = 0x7fffffff;
+    if (c < rows * beams) {
+      const int r = c / beams, k = c % beams;
+      const int seq = b * beams + r;
+      const int tok = s.row_idx[seq * BEAM_MAX + k];
+      float v = s.row_val[seq * BEAM_MAX + k];
+      if (tok != 0x7fffffff) {
+        if (has_length_power) v = v * (1.0f / powf((float)(s.lengths[seq] + 1), length_power));
+        cvv[q] = v; cii[q] = r * n_vocab + tok;
       }
     }
   }
-  for (int k = 0; k < beams; ++k) { cv[tid * BEAM_MAX + k] = lv[k]; ci[tid * BEAM_MAX + k] = li[k]; }
-  __syncthreads();
   for (int sel = 0; sel < beams; ++sel) {
-    float mx = NEG_INF; int arg = 0x7fffffff, pos = -1;
-    for (int k = 0; k < beams; ++k) {
-      const float v = cv[tid * BEAM_MAX + k]; const int id = ci[tid * BEAM_MAX + k];
-      if (v > mx || (v == mx && id < arg)) { mx = v; arg = id; pos = tid * BEAM_MAX + k; }
-    }
+    float bm = NEG_INF; int ba = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (cvv[q] > bm || (cvv[q] == bm && cii[q] < ba)) { bm = cvv[q]; ba = cii[q]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(arg, o, 64);
-      const int op = __shfl_xor(pos, o, 64);
-      if (ov > mx || (ov == mx && oa < arg)) { mx = ov; arg = oa; pos = op; }
+      const float ov = __shfl_xor(bm, o, 64); const int oa = __shfl_xor(ba, o, 64);
+      if (ov > bm || (ov == bm && oa < ba)) { bm = ov; ba = oa; }
     }
-    __syncthreads();
-    if ((tid & 63) == 0) { sh[tid >> 6] = mx; shi[tid >> 6] = arg; shpos[tid >> 6] = pos; }
-    __syncthreads();
-    if (tid == 0) {
-      float bm = sh[0]; int ba = shi[0], bp = shpos[0];
-      for (int w = 1; w < 4; ++w)
-        if (sh[w] > bm || (sh[w] == bm && shi[w] < ba)) { bm = sh[w]; ba = shi[w]; bp = shpos[w]; }
-      s.cand_idx[b * beams + sel] = ba;
-      s.cand_val[b * beams + sel] = bm;
-      if (bp >= 0) { cv[bp] = NEG_INF; ci[bp] = 0x7fffffff; }
-    }
-    __syncthreads();
+    if (lane == 0) { s.cand_idx[b * beams + sel] = ba; s.cand_val[b * beams + sel] = bm; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (cii[q] == ba) { cvv[q] = NEG_INF; cii[q] = 0x7fffffff; }
   }
 }
 
@@ -380,12 +393,12 @@ void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams&
                       hipStream_t stream) {
   const int n_seq = batch * beams;
   hipLaunchKernelGGL(beam_logprob_kernel, dim3(n_seq), dim3(256), 0, stream, s, f, p, n_vocab,
-                     max_steps, pad);
+                     max_steps, pad, beams);
   if (p.sample)
     hipLaunchKernelGGL(beam_sample_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
                        length_power, has_length_power, p.seed);
   else
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(batch), dim3(256), 0, stream, s, beams, n_vocab,
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(batch), dim3(64), 0, stream, s, beams, n_vocab,
                        length_power, has_length_power);
   hipLaunchKernelGGL(beam_reorder_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
                      max_steps, max_len, s_new, eos, pad);

@@ -116,6 +116,8 @@ struct GenState {          // all device pointers; n_seq = batch * beams
   // beam search scratch
   float* cand_val;         // [batch][beams]
   int* cand_idx;           // [batch][beams]
+  float* row_val;          // [n_seq][16]: the `beams` best entries of each sequence's row ...
+  int* row_idx;            // ... and their token ids (beam search, before the per-window merge)
   int* generated_tmp; int* lengths_tmp; int* finished_tmp; int* slot_of_tmp; float* scores_tmp;
 };
 
