@@ -344,3 +344,37 @@ def test_suppress_list_matches_oracle(small):
                                   early_stopping=False)
     ref, _, _ = engine.generate(prompt, max_new_tokens=4, eos_token=999, pad_token=999, early_stopping=False)
     assert (plain == ref).all()          # 'sample' without a temperature is greedy (:826-831)
+
+
+def test_beam_search_finished_beams(small):
+    """Beams that reach EOS: afterwards only the pad token is appended at no cost
+    (generation_utils.py:367-371), lengths exclude the EOS, early stopping ends the loop once the
+    first `num_sentences` beams of every window are finished (:326-330)."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    free, _, _ = engine.generate(prompt, method="beam", num_beams=4, num_sentences=1, max_new_tokens=10,
+                                 eos_token=999, pad_token=999, early_stopping=False)
+    eos = int(free[0, 0, 3])                    # the 4th token of window 0's best beam becomes the EOS
+    kw = dict(num_beams=4, num_sentences=2, max_new_tokens=10)
+    tokens, lengths, scores = engine.generate(prompt, method="beam", eos_token=eos, pad_token=0,
+                                              early_stopping=True, **kw)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        ref = om.beam_search(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), eos=eos, pad=0,
+                             early_stopping=True, **kw)
+    for b in range(3):
+        for s in range(2):
+            row, n = tokens[b, s], int(lengths[b, s])
+            hits = np.where(row == eos)[0]
+            if len(hits):                       # finished: EOS right after the counted tokens, then pad
+                assert hits[0] == n and (row[n + 1:] == 0).all()
+            else:
+                assert n <= 10
+        assert scores[b, 0] >= scores[b, 1] - 1e-4
+    agree = sum(int(np.array_equal(tokens[b, 0], ref["tokens"][b, 0].numpy())) for b in range(3))
+    assert agree >= 2
+    same = [b for b in range(3) if np.array_equal(tokens[b, 0], ref["tokens"][b, 0].numpy())]
+    for b in same:
+        assert lengths[b, 0] == int(ref["lengths"][b, 0])
+        assert abs(scores[b, 0] - float(ref["scores"][b, 0])) < 0.3
