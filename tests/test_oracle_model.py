@@ -10,14 +10,14 @@ from oracle import model as om
 transformers = pytest.importorskip("transformers")
 
 
-def _hf_from_oracle(dims, w):
+def _hf_from_oracle(dims, w, activation="gelu"):
     cfg = transformers.WhisperConfig(
         vocab_size=dims.n_vocab, num_mel_bins=dims.n_mels, d_model=dims.n_audio_state,
         encoder_layers=dims.n_audio_layer, encoder_attention_heads=dims.n_audio_head,
         decoder_layers=dims.n_text_layer, decoder_attention_heads=dims.n_text_head,
         encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
         max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
-        activation_function="gelu", dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+        activation_function=activation, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
         pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1,
         suppress_tokens=None, begin_suppress_tokens=None)
     hf = transformers.WhisperForConditionalGeneration(cfg).eval()
@@ -58,12 +58,15 @@ def _hf_from_oracle(dims, w):
     return hf
 
 
-def test_encoder_and_decoder_match_transformers():
+@pytest.mark.parametrize("approximate, activation", [("none", "gelu"), ("tanh", "gelu_pytorch_tanh")])
+def test_encoder_and_decoder_match_transformers(approximate, activation):
+    """Both GELU forms: exact erf, and the tanh form that Keras 3's `gelu` defaults to and the HIP
+    path runs by default."""
     dims = om.Dims(n_mels=80, n_audio_ctx=100, n_audio_state=64, n_audio_head=2, n_audio_layer=2,
                    n_vocab=300, n_text_ctx=32, n_text_state=64, n_text_head=2, n_text_layer=2)
     w = om.random_weights(dims, seed=3)
-    model = om.Whisper(dims, w, gelu_approximate="none")
-    hf = _hf_from_oracle(dims, w)
+    model = om.Whisper(dims, w, gelu_approximate=approximate)
+    hf = _hf_from_oracle(dims, w, activation)
     g = torch.Generator().manual_seed(0)
     mel = torch.randn(2, 200, 80, generator=g)
     tokens = torch.randint(0, 300, (2, 7), generator=g)
