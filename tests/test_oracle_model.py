@@ -61,7 +61,10 @@ def _hf_from_oracle(dims, w, activation="gelu"):
 @pytest.mark.parametrize("approximate, activation", [("none", "gelu"), ("tanh", "gelu_pytorch_tanh")])
 def test_encoder_and_decoder_match_transformers(approximate, activation):
     """Both GELU forms: exact erf, and the tanh form that Keras 3's `gelu` defaults to and the HIP
-    path runs by default."""
+    path runs by default.  transformers hard-codes the exact form in the convolution stem whatever
+    the configured activation is, so with the tanh form the encoder outputs may differ by the
+    difference of the two forms there (about 1e-3) and the decoder is compared on the oracle's
+    own encoder output."""
     dims = om.Dims(n_mels=80, n_audio_ctx=100, n_audio_state=64, n_audio_head=2, n_audio_layer=2,
                    n_vocab=300, n_text_ctx=32, n_text_state=64, n_text_head=2, n_text_layer=2)
     w = om.random_weights(dims, seed=3)
@@ -73,9 +76,9 @@ def test_encoder_and_decoder_match_transformers(approximate, activation):
     with torch.no_grad():
         enc = model.encoder(mel)
         enc_hf = hf.model.encoder(mel.permute(0, 2, 1)).last_hidden_state
-        assert torch.allclose(enc, enc_hf, atol=2e-4), (enc - enc_hf).abs().max()
+        assert torch.allclose(enc, enc_hf, atol=2e-4 if approximate == "none" else 5e-3), (enc - enc_hf).abs().max()
         logits, cache = model.decoder(tokens, model.cross_kv(enc))
-        logits_hf = hf(decoder_input_ids=tokens, encoder_outputs=(enc_hf,)).logits
+        logits_hf = hf(decoder_input_ids=tokens, encoder_outputs=(enc,)).logits
         assert torch.allclose(logits, logits_hf, atol=5e-4), (logits - logits_hf).abs().max()
         # incremental decoding with the cache equals the full pass
         l1, c1 = model.decoder(tokens[:, :4], model.cross_kv(enc))
