@@ -39,20 +39,27 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--replicas", type=int, default=2,
                     help="whisper: 2 adds the pipelined two-engine measurement, 1 skips it")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--whisper-steps", type=int, default=2,
                     help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
     return ap.parse_args()
 
 
-def init_dist(n):
+def init_dist(n, backend="nccl"):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())       # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local
 
 
@@ -66,10 +73,22 @@ def barrier(world):
 def max_over_ranks(x, world):
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
+
+
+def all_ranks_ok(ok, world):
+    """True when every rank says ok.  A collective that failed ranks reach too, so that a rank
+    whose leg raised (out of memory, ...) does not leave the others waiting in a barrier."""
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+    return bool(ok)
 
 
 # HBM bytes per logmel_main launch from the rocprofv3 PMC passes of this build (FETCH_SIZE x 2,
@@ -208,31 +227,42 @@ def bench_whisper(args, rank, world, steps, warmup, with_cpu):
     from speech_to_text_amd.weights import random_whisper_weights
 
     dims = whisper_dims(args.model)
-    weights = random_whisper_weights(dims, 0)
     prompt_row = [50258, 50259, 50359]
-    eng = WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
-                        max_text_len=args.new_tokens + len(prompt_row) + 1, max_prompt_len=4)
-    fn = WhisperSTFT(n_mel_channels=dims["n_mels"])
-    dev = torch.device("cuda", torch.cuda.current_device())
-    rng = np.random.default_rng(100 + rank)
-    pcm = torch.from_numpy(rng.uniform(-1, 1, args.batch * 480000).astype(np.float32)).to(dev)
-    prompt = np.array([prompt_row] * args.batch, dtype=np.int32)
+    err = None
+    try:
+        weights = random_whisper_weights(dims, 0)
+        eng = WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
+                            max_text_len=args.new_tokens + len(prompt_row) + 1, max_prompt_len=4)
+        fn = WhisperSTFT(n_mel_channels=dims["n_mels"])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rng = np.random.default_rng(100 + rank)
+        pcm = torch.from_numpy(rng.uniform(-1, 1, args.batch * 480000).astype(np.float32)).to(dev)
+        prompt = np.array([prompt_row] * args.batch, dtype=np.int32)
 
-    def step():
-        mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])       # 30 s = 3000 frames exactly
-        eng.encode(mel)
-        return eng.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
-                            early_stopping=False)
+        def step():
+            mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])       # 30 s = 3000 frames exactly
+            eng.encode(mel)
+            return eng.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
+                                early_stopping=False)
 
-    for _ in range(warmup):
-        step()
+        for _ in range(warmup):
+            step()
+    except Exception as e:                  # noqa: BLE001
+        err = e
+    if not all_ranks_ok(err is None, world):
+        raise err if err is not None else RuntimeError("another rank failed to set up the whisper leg")
     barrier(world)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        toks, lens, _ = step()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(steps):
+            toks, lens, _ = step()
+        torch.cuda.synchronize()
+    except Exception as e:                  # noqa: BLE001
+        err = e
     dt = time.perf_counter() - t0
     barrier(world)
+    if not all_ranks_ok(err is None, world):
+        raise err if err is not None else RuntimeError("another rank failed in the whisper leg")
     dt = max_over_ranks(dt, world)
 
     # encoder alone (MFMA-bound part), event-timed on the launching stream
@@ -282,7 +312,10 @@ def bench_whisper(args, rank, world, steps, warmup, with_cpu):
                                "restatement (oracle/model.py) on the same weights" % (n_tok, args.new_tokens),
                                "first_tokens_match_gpu": bool((ref["tokens"][0].numpy() == toks[0][:n_tok]).all())}
     if args.replicas >= 2:
-        out["pipelined"] = bench_whisper_pipelined(args, dims, weights, eng, fn, pcm, prompt, world, steps)
+        try:                                # every rank raises together (all_ranks_ok)
+            out["pipelined"] = bench_whisper_pipelined(args, dims, weights, eng, fn, pcm, prompt, world, steps)
+        except Exception as e:              # noqa: BLE001
+            out["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del eng
     return out
 
@@ -295,12 +328,16 @@ def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, 
     import threading
     from speech_to_text_amd.audio.stft import WhisperSTFT
     from speech_to_text_amd.engine import WhisperEngine
-    engs = [eng0, WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
-                                max_text_len=args.new_tokens + 8, max_prompt_len=4)]
-    fns = [fn0, WhisperSTFT(n_mel_channels=dims["n_mels"])]     # a log-mel plan serves one stream
     dev = pcm.device
     first = threading.Event()
     box, errors = {}, []
+    engs, fns = [eng0], [fn0]
+    try:
+        engs.append(WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
+                                  max_text_len=args.new_tokens + 8, max_prompt_len=4))
+        fns.append(WhisperSTFT(n_mel_channels=dims["n_mels"]))    # a log-mel plan serves one stream
+    except Exception as e:                   # noqa: BLE001
+        errors.append(e)
 
     def one(r, signal=False):
         mel = fns[r](pcm)[0].view(args.batch, 3000, dims["n_mels"])
@@ -326,8 +363,14 @@ def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, 
         finally:
             first.set()
 
-    one(1)                                   # warm the second engine (the first one is warm)
-    torch.cuda.synchronize()
+    try:
+        if not errors:
+            one(1)                           # warm the second engine (the first one is warm)
+            torch.cuda.synchronize()
+    except Exception as e:                   # noqa: BLE001
+        errors.append(e)
+    if not all_ranks_ok(not errors, world):
+        raise errors[0] if errors else RuntimeError("another rank failed to set up the pipelined leg")
     barrier(world)
     t0 = time.perf_counter()
     threads = [threading.Thread(target=worker, args=(r, steps)) for r in range(2)]
@@ -338,9 +381,9 @@ def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier(world)
+    if not all_ranks_ok(not errors, world):
+        raise errors[0] if errors else RuntimeError("another rank failed in the pipelined leg")
     dt = max_over_ranks(dt, world)
-    if errors:
-        raise errors[0]
     return {"value": round(world * 2 * steps * args.batch * 30.0 / dt, 1), "unit": "audio-s/s",
             "replicas": 2, "steps_per_replica": steps, "seconds": round(dt, 3),
             "note": "two engines per GPU, encode of one batch overlapped with decode of the other"}
@@ -348,7 +391,7 @@ def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, 
 
 def main():
     args = parse()
-    rank, world, local = init_dist(args.gpus)
+    rank, world, local = init_dist(args.gpus, args.dist_backend)
     if args.workload == "logmel":
         line = bench_logmel(args, rank, world)
         if args.whisper_steps > 0:
@@ -356,9 +399,7 @@ def main():
             try:
                 line["whisper"] = bench_whisper(args, rank, world, args.whisper_steps, 1,
                                                 not args.no_cpu_baseline)
-            except Exception as e:          # noqa: BLE001
-                if world > 1:
-                    raise                   # ranks must not diverge around collectives
+            except Exception as e:          # noqa: BLE001  (every rank raises together: all_ranks_ok)
                 line["whisper"] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         w = bench_whisper(args, rank, world, args.steps, args.warmup, not args.no_cpu_baseline)
