@@ -290,6 +290,30 @@ def bench_whisper(args, rank, world, steps, warmup, with_cpu):
         "roofline_decode": decode_roofline(dims, args.batch, (dt / steps * 1e3 - enc_ms) / args.new_tokens),
         "tokens_generated_per_window": int(lens[0]),
     }
+    if args.batch > 32:
+        # the batch size BASELINE.json's configs[3] names (32 windows per GPU), on the same engine;
+        # this rank's own time (no collective), scaled by the number of ranks
+        try:
+            p32 = prompt[:32]
+
+            def step32():
+                mel32 = fn(pcm[: 32 * 480000])[0].view(32, 3000, dims["n_mels"])
+                eng.encode(mel32)
+                eng.generate(p32, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
+                             early_stopping=False)
+
+            step32()
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(2):
+                step32()
+            torch.cuda.synchronize()
+            t32 = (time.perf_counter() - t32) / 2
+            out["batch32"] = {"value": round(world * 32 * 30.0 / t32, 1), "unit": "audio-s/s",
+                              "ms_per_step": round(t32 * 1e3, 2),
+                              "note": "32 windows per GPU and step (BASELINE.json configs[3] batch size), rank 0's time"}
+        except Exception as e:              # noqa: BLE001
+            out["batch32"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if with_cpu and rank == 0 and world == 1:
         from oracle import model as om
         threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
