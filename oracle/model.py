@@ -62,9 +62,19 @@ class Dims:
         return Dims(m, 1500, d, h, l, v, 448, d, h, l)
 
 
-def random_weights(dims, seed=0, dtype=torch.float32):
+def random_weights(dims, seed=0, dtype=torch.float32, style="plain"):
     """Seeded synthetic weights of the right shapes (no checkpoint ships with the
-    reference).  Scaled so that activations stay O(1) through the stack."""
+    reference).  Scaled so that activations stay O(1) through the stack.
+
+    style="plain": with the tied embedding at std 0.3 the input token dominates its own logit,
+    so a greedy decode repeats the last prompt token whatever the audio - fine for encoder
+    states and teacher-forced logits, useless as a generation test.
+    style="peaked": same draws, rescaled afterwards (small embedding and positions, final
+    LayerNorm gain 6, every query matrix x4 for sharp attention, decoder attention outputs x2,
+    rows of every second MLP matrix centred so that the positive mean of the GELU outputs does
+    not add the same vector at every position of a deep stack) so that the next token depends
+    on the audio (cross-attention) and on the history (self-attention) and the winner usually
+    leads by about a nat."""
     g = torch.Generator().manual_seed(seed)
     w = {}
 
@@ -101,6 +111,22 @@ def random_weights(dims, seed=0, dtype=torch.float32):
         ln(p + "mlp_ln", d)
         lin(p + "mlp.0", 4 * d, d); lin(p + "mlp.2", d, 4 * d, scale=0.5)
     ln("decoder.ln", d)
+    if style == "peaked":
+        for k in w:
+            if k == "decoder.token_embedding.weight":
+                w[k] = w[k] * (0.05 / 0.3)
+            elif k == "decoder.positional_embedding":
+                w[k] = w[k] * 0.5
+            elif k == "decoder.ln.weight":
+                w[k] = w[k] * 6.0
+            elif k.endswith("query.weight"):
+                w[k] = w[k] * 4.0
+            elif k.startswith("decoder.") and k.endswith("attn.out.weight"):
+                w[k] = w[k] * 2.0
+            elif k.endswith("mlp.2.weight"):
+                w[k] = w[k] - w[k].mean(dim=1, keepdim=True)
+    elif style != "plain":
+        raise ValueError("unknown style %r" % (style,))
     return {k: v.to(dtype) for k, v in w.items()}
 
 

@@ -562,7 +562,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   auto select = [&](int s_new) {
     if (p->method == STT_METHOD_BEAM)
       launch_beam_step(gs, f, lp, batch, beams, nsent, V, max_steps, e->max_len, s_new, p->eos_token,
-                       p->pad_token, p->length_power, p->has_length_power, st);
+                       p->pad_token, p->length_power, p->has_length_power, p->early_stopping, st);
     else
       launch_greedy_step(gs, f, lp, n_seq, V, max_steps, s_new, p->eos_token, p->pad_token, st);
   };

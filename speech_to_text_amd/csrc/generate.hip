@@ -372,9 +372,14 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const GenState s, int
   }
 }
 
+// `freeze`: early stopping is on.  The host polls "all finished" only every few steps, so steps
+// may still be replayed after the one that finished the first `num_sentences` beams of every
+// window; the reference stops right there (generation_utils.py:326-330), so from then on nothing
+// is committed (unfinished lower beams must not overtake the finished ones afterwards).
 __global__ __launch_bounds__(256) void beam_commit_kernel(const GenState s, int max_steps,
-                                                          int max_len, int s_new) {
+                                                          int max_len, int s_new, int freeze) {
   const int i = blockIdx.x;
+  if (freeze && *s.all_finished) return;
   for (int j = threadIdx.x; j < max_steps; j += 256)
     s.generated[(long)i * max_steps + j] = s.generated_tmp[(long)i * max_steps + j];
   for (int p = threadIdx.x; p < max_len; p += 256)
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(256) void beam_commit_kernel(const GenState s, int 
 void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int batch,
                       int beams, int num_sentences, int n_vocab, int max_steps, int max_len,
                       int s_new, int eos, int pad, float length_power, int has_length_power,
-                      hipStream_t stream) {
+                      int early_stopping, hipStream_t stream) {
   const int n_seq = batch * beams;
   hipLaunchKernelGGL(beam_logprob_kernel, dim3(n_seq), dim3(256), 0, stream, s, f, p, n_vocab,
                      max_steps, pad, beams);
@@ -403,7 +408,7 @@ void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams&
   hipLaunchKernelGGL(beam_reorder_kernel, dim3(n_seq), dim3(256), 0, stream, s, beams, n_vocab,
                      max_steps, max_len, s_new, eos, pad);
   hipLaunchKernelGGL(beam_commit_kernel, dim3(n_seq), dim3(256), 0, stream, s, max_steps, max_len,
-                     s_new);
+                     s_new, early_stopping);
   hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(256), 0, stream, s, n_seq, beams,
                      num_sentences);
 }

@@ -151,4 +151,4 @@ void launch_prepare_step(const GenState& s, int* tokens_in, int* positions, int 
 void launch_beam_step(const GenState& s, const FilterArgs& f, const LogitParams& p, int batch,
                       int beams, int num_sentences, int n_vocab, int max_steps, int max_len,
                       int s_new, int eos, int pad, float length_power, int has_length_power,
-                      hipStream_t stream);
+                      int early_stopping, hipStream_t stream);

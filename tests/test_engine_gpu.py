@@ -5,18 +5,10 @@ import pytest
 import torch
 
 from oracle import model as om
+from tests import _parity as P
+from tests._parity import bf16_round as _bf16_round, dims_dict as _dims_dict, rel_l2 as _rel_l2
 
 pytestmark = pytest.mark.gpu
-
-
-def _dims_dict(d):
-    return {k: getattr(d, k) for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head",
-                                        "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
-                                        "n_text_head", "n_text_layer")}
-
-
-def _bf16_round(w):
-    return {k: v.to(torch.bfloat16).float() for k, v in w.items()}
 
 
 @pytest.fixture(scope="module")
@@ -24,16 +16,14 @@ def small():
     from speech_to_text_amd.engine import WhisperEngine
     dims = om.Dims(n_mels=80, n_audio_ctx=1500, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
                    n_vocab=1000, n_text_ctx=64, n_text_state=128, n_text_head=2, n_text_layer=2)
-    w = _bf16_round(om.random_weights(dims, seed=0))
-    engine = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=4, max_text_len=48, max_prompt_len=8)
+    # "peaked" weights: the generated ids depend on the audio and the history (with the plain
+    # ones every decode repeats the last prompt token, which tests nothing)
+    w = _bf16_round(om.random_weights(dims, seed=0, style="peaked"))
+    engine = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=5, max_text_len=48, max_prompt_len=8)
     oracle = om.Whisper(dims, w)
     g = torch.Generator().manual_seed(1)
     mel = (torch.rand(3, 3000, 80, generator=g) * 2 - 1)
     return dims, engine, oracle, mel
-
-
-def _rel_l2(a, b):
-    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
 def test_encoder_states(small):
@@ -44,7 +34,7 @@ def test_encoder_states(small):
     assert got.shape == ref.shape == (3, 1500, 128)
     # stated bf16 tolerance: relative L2 <= 1e-2 and max abs <= 0.05 * std(ref)
     assert _rel_l2(got, ref) < 1e-2
-    assert np.abs(got - ref).max() < 0.05 * ref.std() * 4
+    assert np.abs(got - ref).max() < 0.05 * ref.std()
 
 
 def test_short_window_is_zero_padded(small):
@@ -97,41 +87,10 @@ def _long_prompt_engine(dims):
     """Same weights as `small`, room for 3 x 48 rows in one decoder pass."""
     if "e" not in _LONG:
         from speech_to_text_amd.engine import WhisperEngine
-        w = _bf16_round(om.random_weights(dims, seed=0))
+        w = _bf16_round(om.random_weights(dims, seed=0, style="peaked"))
         _LONG["e"] = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=1, max_text_len=60,
                                    max_prompt_len=48)
     return _LONG["e"]
-
-
-def _check_tokens_against_oracle(oracle, enc, prompt, tokens, eos, pad, margin=0.05, logits_filter=None):
-    """Teacher-force the oracle on the GPU's tokens: at every step the GPU token must be the
-    oracle's argmax, or lose to it by less than `margin` in log-probability (bf16 near-tie)."""
-    b, steps = tokens.shape
-    cross = oracle.cross_kv(enc)
-    cache, offset, inputs = None, 0, torch.from_numpy(prompt).long()
-    lengths = torch.full((b,), prompt.shape[1])
-    finished = torch.zeros(b, dtype=torch.bool)
-    gen = torch.from_numpy(tokens).long()
-    exact = total = 0
-    for t in range(steps):
-        logits, cache = oracle.decoder(inputs, cross, cache, offset)
-        offset += inputs.shape[1]
-        lp = om.process_logits(logits[:, -1], lengths, gen, t, logits_filter=logits_filter)
-        for i in range(b):
-            if finished[i]:
-                assert tokens[i, t] == pad
-                continue
-            total += 1
-            best = int(lp[i].argmax())
-            if best == tokens[i, t]:
-                exact += 1
-            else:
-                assert float(lp[i, best] - lp[i, tokens[i, t]]) < margin, (i, t, best, tokens[i, t])
-        tok = gen[:, t]
-        finished = finished | (tok == eos)
-        lengths = lengths + (~finished).long()
-        inputs = tok[:, None]
-    return exact, total
 
 
 def test_greedy_tokens(small):
@@ -140,17 +99,18 @@ def test_greedy_tokens(small):
     prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
     tokens, lengths, scores = engine.generate(prompt, max_new_tokens=20, eos_token=999, pad_token=999,
                                               early_stopping=False)
+    assert tokens.shape == (3, 20)
     with torch.no_grad():
         enc = oracle.encoder(mel)
         ref = om.greedy(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), max_new_tokens=20,
                         eos=999, pad=999, early_stopping=False)
-        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 999, 999)
-    assert tokens.shape == (3, 20)
-    assert exact >= total - 2
-    same = (tokens == ref["tokens"].numpy()).all(axis=1)
-    for i in np.where(same)[0]:
-        assert abs(scores[i] - float(ref["scores"][i])) < 0.05 * 20
-        assert lengths[i] == int(ref["lengths"][i])
+        # every step: the oracle's argmax, or within the near-tie allowance of it (asserted inside)
+        exact, total = P.check_greedy_steps(oracle, enc, prompt, tokens, 999, 999, scores=scores)
+    assert total == 60
+    assert len(set(tokens.reshape(-1).tolist())) > 6      # the decode is not a degenerate repeat
+    if exact == total:                                    # no near-tie met: the free-running decodes agree
+        assert np.array_equal(tokens, ref["tokens"].numpy())
+        assert np.array_equal(lengths, ref["lengths"].numpy())
 
 
 def test_greedy_eos_and_suppress_list(small):
@@ -162,30 +122,50 @@ def test_greedy_eos_and_suppress_list(small):
     tokens, lengths, scores = engine.generate(prompt, max_new_tokens=8, eos_token=eos, pad_token=0)
     first = int(np.argmax(free[0] == eos))
     assert lengths[0] == first and (tokens[0, first + 1:] == 0).all() and tokens[0, first] == eos
+    with torch.no_grad():
+        enc = oracle.encoder(mel[:2])
+        P.check_greedy_steps(oracle, enc, prompt, tokens, eos, 0, scores=scores)
     banned = [int(free[1, 0])]
     t2, _, _ = engine.generate(prompt, max_new_tokens=4, eos_token=999, pad_token=999,
                                early_stopping=False, logits_filter=banned)
     assert banned[0] not in t2[1].tolist()
 
 
-def test_beam_search(small):
+def test_length_temperature(small):
+    """`length_temperature` (generation_utils.py:505-507) multiplies the logits by
+    (length + 1) ** t before the log-softmax: the greedy ids stay, the scores change."""
     dims, engine, oracle, mel = small
     engine.encode(mel)
     prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    kw = dict(max_new_tokens=12, eos_token=999, pad_token=999, early_stopping=False)
+    plain, _, s0 = engine.generate(prompt, **kw)
+    tokens, _, s1 = engine.generate(prompt, length_temperature=-0.5, **kw)
+    assert np.abs(s0 - s1).max() > 0.5
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        P.check_greedy_steps(oracle, enc, prompt, tokens, 999, 999, length_temperature=-0.5, scores=s1)
+        n = P.check_beam_steps(engine, oracle, enc, prompt, 3, 5, 999, 999, length_temperature=0.3)
+    assert n == 15
+
+
+def test_beam_search(small):
+    """Every transition of every window against the oracle (tests/_parity.py), then the
+    properties of the returned sentences."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 4, 10, 999, 999) == 30
     tokens, lengths, scores = engine.generate(prompt, method="beam", num_beams=4, num_sentences=2,
                                               max_new_tokens=10, eos_token=999, pad_token=999,
                                               early_stopping=False)
     assert tokens.shape == (3, 2, 10)
-    with torch.no_grad():
-        enc = oracle.encoder(mel)
-        ref = om.beam_search(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), num_beams=4,
-                             num_sentences=2, max_new_tokens=10, eos=999, pad=999, early_stopping=False)
-        g = om.greedy(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), max_new_tokens=10,
-                      eos=999, pad=999, early_stopping=False)
     assert (scores[:, 0] >= scores[:, 1] - 1e-4).all()
-    assert (scores[:, 0] >= g["scores"].numpy() - 0.2).all()
     # the score of each returned sequence equals the oracle's teacher-forced log-probability
     with torch.no_grad():
+        g = om.greedy(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), max_new_tokens=10,
+                      eos=999, pad=999, early_stopping=False)
         for b in range(3):
             seq = torch.from_numpy(tokens[b, 0]).long()[None]
             full = torch.cat([torch.from_numpy(prompt[b:b + 1]).long(), seq], dim=1)
@@ -193,8 +173,21 @@ def test_beam_search(small):
             lp = torch.log_softmax(logits[0, 2:], dim=-1)
             want = float(lp.gather(1, seq[0][:, None]).sum())
             assert abs(want - scores[b, 0]) < 0.3
-    agree = (tokens[:, 0] == ref["tokens"][:, 0].numpy()).all(axis=1).sum()
-    assert agree >= 2
+
+
+def test_beam_search_length_power(small):
+    """`length_power` (generation_utils.py:372-374): candidates ranked by score / (length + 1) ** p,
+    with an EOS that beams do reach so that lengths differ between beams."""
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    free, _, _ = engine.generate(prompt, method="beam", num_beams=4, num_sentences=1, max_new_tokens=8,
+                                 eos_token=999, pad_token=999, early_stopping=False)
+    eos = int(free[0, 0, 2])
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 4, 8, eos, 0, length_power=0.7) == 24
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 4, 8, eos, 0, length_power=2.0) == 24
 
 
 def test_timestamp_filter(small):
@@ -204,18 +197,35 @@ def test_timestamp_filter(small):
     prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
     filt = TimestampFilter(remove_tokens=[10, 11, 12], remove_tokens_with_space=[10, 11, 12, 13, 900],
                            timestamp_begin_idx=920, eos_token_idx=900)
-    tokens, lengths, _ = engine.generate(prompt, max_new_tokens=12, eos_token=900, pad_token=900,
-                                         early_stopping=False, logits_filter=filt)
+    tokens, lengths, scores = engine.generate(prompt, max_new_tokens=12, eos_token=900, pad_token=900,
+                                              early_stopping=False, logits_filter=filt)
     assert (tokens[:, 0] == 920).all()
     cfg = om.FilterConfig(remove_tokens=(10, 11, 12), remove_tokens_first=(10, 11, 12, 13, 900),
                           timestamp_begin=920, eos=900)
     with torch.no_grad():
         enc = oracle.encoder(mel)
-        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 900, 900, logits_filter=cfg)
-    assert exact >= total - 2
+        P.check_greedy_steps(oracle, enc, prompt, tokens, 900, 900, logits_filter=cfg, scores=scores)
     for row in tokens:
         ts = row >= 920
         assert not (ts[:-2] & ts[1:-1] & ts[2:]).any()      # never three timestamps in a row
+
+
+def test_beam_search_with_timestamp_filter(small):
+    """Beam search and the Whisper timestamp rules together (whisper.py:354-416 inside
+    generation_utils.py:333-438), 5 beams: every transition against the oracle."""
+    from speech_to_text_amd.engine import TimestampFilter
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    filt = TimestampFilter(remove_tokens=[10, 11, 12], remove_tokens_with_space=[10, 11, 12, 13, 900],
+                           timestamp_begin_idx=920, eos_token_idx=900)
+    cfg = om.FilterConfig(remove_tokens=(10, 11, 12), remove_tokens_first=(10, 11, 12, 13, 900),
+                          timestamp_begin=920, eos=900)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        n = P.check_beam_steps(engine, oracle, enc, prompt, 5, 12, 900, 900, engine_filter=filt,
+                               oracle_filter=cfg)
+    assert n == 36
 
 
 def test_encoder_states_width_256():
@@ -224,25 +234,23 @@ def test_encoder_states_width_256():
     from speech_to_text_amd.engine import WhisperEngine
     dims = om.Dims(n_mels=80, n_audio_ctx=1500, n_audio_state=256, n_audio_head=4, n_audio_layer=2,
                    n_vocab=1000, n_text_ctx=64, n_text_state=256, n_text_head=4, n_text_layer=1)
-    w = _bf16_round(om.random_weights(dims, seed=3))
+    w = _bf16_round(om.random_weights(dims, seed=3, style="peaked"))
     engine = WhisperEngine(_dims_dict(dims), w, max_batch=3, max_beams=1, max_text_len=16, max_prompt_len=4)
     oracle = om.Whisper(dims, w)
     g = torch.Generator().manual_seed(4)
     mel = (torch.rand(3, 3000, 80, generator=g) * 2 - 1)
     got = engine.encode(mel, return_output=True).cpu().numpy()
     with torch.no_grad():
-        ref = oracle.encoder(mel).numpy()
+        enc = oracle.encoder(mel)
+    ref = enc.numpy()
     assert _rel_l2(got, ref) < 1e-2
-    assert np.abs(got - ref).max() < 0.05 * ref.std() * 4
-    # and the decoder on top of it: greedy tokens identical to the oracle
+    assert np.abs(got - ref).max() < 0.05 * ref.std()
+    # and the decoder on top of it
     prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
-    toks, lens, _ = engine.generate(prompt, max_new_tokens=8, eos_token=999, pad_token=999,
-                                    early_stopping=False)
+    toks, lens, scores = engine.generate(prompt, max_new_tokens=8, eos_token=999, pad_token=999,
+                                         early_stopping=False)
     with torch.no_grad():
-        refg = om.greedy(oracle, mel, torch.tensor(prompt.astype(np.int64)), max_new_tokens=8, eos=999,
-                         pad=999, early_stopping=False)
-    assert (toks[:, 0, :8] == refg["tokens"].numpy()[:, :8]).all() if toks.ndim == 3 else \
-        (toks[:, :8] == refg["tokens"].numpy()[:, :8]).all()
+        P.check_greedy_steps(oracle, enc, prompt, toks, 999, 999, scores=scores)
 
 
 def test_greedy_sampling(small):
@@ -338,8 +346,7 @@ def test_suppress_list_matches_oracle(small):
     assert set(tokens.reshape(-1).tolist()) <= survivors
     with torch.no_grad():
         enc = oracle.encoder(mel)
-        exact, total = _check_tokens_against_oracle(oracle, enc, prompt, tokens, 999, 999, logits_filter=banned)
-    assert exact >= total - 2
+        P.check_greedy_steps(oracle, enc, prompt, tokens, 999, 999, logits_filter=banned)
     plain, _, _ = engine.generate(prompt, method="sample", max_new_tokens=4, eos_token=999, pad_token=999,
                                   early_stopping=False)
     ref, _, _ = engine.generate(prompt, max_new_tokens=4, eos_token=999, pad_token=999, early_stopping=False)
@@ -361,8 +368,9 @@ def test_beam_search_finished_beams(small):
                                               early_stopping=True, **kw)
     with torch.no_grad():
         enc = oracle.encoder(mel)
-        ref = om.beam_search(oracle, enc=enc, prompt=torch.from_numpy(prompt).long(), eos=eos, pad=0,
-                             early_stopping=True, **kw)
+        # every transition of every window, finished beams included (pad appended at no cost,
+        # lengths frozen): asserted inside
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 4, 10, eos, 0) == 30
     for b in range(3):
         for s in range(2):
             row, n = tokens[b, s], int(lengths[b, s])
@@ -372,9 +380,21 @@ def test_beam_search_finished_beams(small):
             else:
                 assert n <= 10
         assert scores[b, 0] >= scores[b, 1] - 1e-4
-    agree = sum(int(np.array_equal(tokens[b, 0], ref["tokens"][b, 0].numpy())) for b in range(3))
-    assert agree >= 2
-    same = [b for b in range(3) if np.array_equal(tokens[b, 0], ref["tokens"][b, 0].numpy())]
-    for b in same:
-        assert lengths[b, 0] == int(ref["lengths"][b, 0])
-        assert abs(scores[b, 0] - float(ref["scores"][b, 0])) < 0.3
+    # early stopping (generation_utils.py:326-330): the state returned is the one of the first step
+    # after which the first `num_sentences` beams of every window are finished, whatever the
+    # engine's host-side polling interval.  All but four tokens are banned so that every window
+    # gets there within a few steps.
+    survivors = {7, 123, 500, 998}
+    banned = [i for i in range(dims.n_vocab) if i not in survivors]
+    kw = dict(method="beam", num_beams=4, num_sentences=2, eos_token=998, pad_token=0, logits_filter=banned)
+    stop = None
+    for t in range(1, 17):
+        ft, fl, fs = engine.generate(prompt, max_new_tokens=t, early_stopping=False, **kw)
+        if (ft == 998).any(axis=2).all():
+            stop = t
+            break
+    assert stop is not None and stop < 16, "no step at which every window's two best beams are finished"
+    for check_every in (1, 8):
+        et, el, es = engine.generate(prompt, max_new_tokens=16, early_stopping=True, check_every=check_every, **kw)
+        assert np.array_equal(et[:, :, :stop], ft) and (et[:, :, stop:] == 0).all()
+        assert np.array_equal(el, fl) and np.allclose(es, fs, atol=1e-5)
