@@ -170,47 +170,69 @@ def attention(q, k, v, mask=None):
 
 
 class Whisper:
-    def __init__(self, dims, weights, gelu_approximate="tanh"):
+    """`round_acts=False`: the reference's arithmetic, float32 throughout.
+
+    `round_acts=True`: the same network with every tensor that the MI355X engine keeps in bf16
+    rounded to bf16 at the same place (GEMM inputs, stored Q/K/V, encoder attention weights before
+    the P V product, attention and first-MLP outputs, encoder output, cross K/V); sums, residual
+    stream, LayerNorm, softmax and logits stay float32.  It is not the reference: it separates,
+    in a test, what bf16 storage costs (engine vs this) from what an error would look like
+    (engine vs the float32 oracle has to stay inside the stated bf16 tolerance either way)."""
+
+    def __init__(self, dims, weights, gelu_approximate="tanh", round_acts=False):
         self.dims = dims
         self.w = {k: v.float() for k, v in weights.items()}
         self.act = gelu_approximate
         self.pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state)
+        self.round_acts = round_acts
+
+    def r(self, x):
+        return x.to(torch.bfloat16).float() if self.round_acts else x
+
+    def _attention(self, q, k, v, mask=None, round_p=False):
+        if not (self.round_acts and round_p):
+            return attention(q, k, v, mask)
+        # flash-style: weights relative to the row maximum, rounded for the P V product, the
+        # normaliser summed from the unrounded ones
+        logits = torch.einsum("bhij,bhkj->bhik", q, k) / math.sqrt(q.shape[-1])
+        p = torch.exp(logits - logits.max(dim=-1, keepdim=True).values)
+        return torch.matmul(self.r(p), v) / p.sum(dim=-1, keepdim=True)
 
     # ------------------------------------------------------------- encoder
     def stem(self, mel):
         """mel [B, 3000, n_mels] -> [B, 1500, d] (whisper_arch.py:140-155)."""
         w = self.w
-        x = mel.float().permute(0, 2, 1)
-        x = gelu(F.conv1d(x, w["encoder.conv1.weight"], w["encoder.conv1.bias"], padding=1), self.act)
+        x = self.r(mel.float()).permute(0, 2, 1)
+        x = self.r(gelu(F.conv1d(x, w["encoder.conv1.weight"], w["encoder.conv1.bias"], padding=1), self.act))
         x = gelu(F.conv1d(x, w["encoder.conv2.weight"], w["encoder.conv2.bias"], stride=2, padding=1), self.act)
         x = x.permute(0, 2, 1)
         return x + self.pos[None, : x.shape[1]]
 
-    def _self_block(self, x, p, n_head, mask=None, cache=None):
+    def _self_block(self, x, p, n_head, mask=None, cache=None, round_p=False):
         """x + out(attn(LN(x))) (rmha.py:210-315); cache = (k, v) of earlier positions."""
-        w = self.w
-        h = layer_norm(x, w, p + "attn_ln")
-        q = _split(linear(h, w, p + "attn.query"), n_head)
-        k = _split(linear(h, w, p + "attn.key"), n_head)
-        v = _split(linear(h, w, p + "attn.value"), n_head)
+        w, r = self.w, self.r
+        h = r(layer_norm(x, w, p + "attn_ln"))
+        q = _split(r(linear(h, w, p + "attn.query")), n_head)
+        k = _split(r(linear(h, w, p + "attn.key")), n_head)
+        v = _split(r(linear(h, w, p + "attn.value")), n_head)
         if cache is not None:
             k = torch.cat([cache[0], k], dim=2)
             v = torch.cat([cache[1], v], dim=2)
-        o = linear(_merge(attention(q, k, v, mask)), w, p + "attn.out")
+        o = linear(r(_merge(self._attention(q, k, v, mask, round_p))), w, p + "attn.out")
         return x + o, (k, v)
 
     def _mlp_block(self, x, p):
         """ffn(LN(x)) + x with normalize='middle' (transformer_arch.py:478-492)."""
-        w = self.w
-        h = layer_norm(x, w, p + "mlp_ln")
-        return x + linear(gelu(linear(h, w, p + "mlp.0"), self.act), w, p + "mlp.2")
+        w, r = self.w, self.r
+        h = r(layer_norm(x, w, p + "mlp_ln"))
+        return x + linear(r(gelu(linear(h, w, p + "mlp.0"), self.act)), w, p + "mlp.2")
 
     def encoder(self, mel, return_layers=False):
         x = self.stem(mel)
         layers = [x]
         for i in range(self.dims.n_audio_layer):
             p = "encoder.blocks.%d." % i
-            x, _ = self._self_block(x, p, self.dims.n_audio_head)
+            x, _ = self._self_block(x, p, self.dims.n_audio_head, round_p=True)
             x = self._mlp_block(x, p)
             layers.append(x)
         out = layer_norm(x, self.w, "encoder.ln_post")
@@ -220,11 +242,12 @@ class Whisper:
     def cross_kv(self, enc):
         """Per layer (k, v) of the encoder output, computed once per window
         (rmha.py:241-245: no LayerNorm on the encoder output, key has no bias)."""
-        kv = []
+        kv, r = [], self.r
+        enc = r(enc)
         for i in range(self.dims.n_text_layer):
             p = "decoder.blocks.%d.cross_attn." % i
-            kv.append((_split(linear(enc, self.w, p + "key"), self.dims.n_text_head),
-                       _split(linear(enc, self.w, p + "value"), self.dims.n_text_head)))
+            kv.append((_split(r(linear(enc, self.w, p + "key")), self.dims.n_text_head),
+                       _split(r(linear(enc, self.w, p + "value")), self.dims.n_text_head)))
         return kv
 
     def decoder(self, tokens, cross, cache=None, offset=0):
@@ -244,12 +267,15 @@ class Whisper:
             p = "decoder.blocks.%d." % i
             x, kv = self._self_block(x, p, dims.n_text_head, mask, None if cache is None else cache[i])
             new_cache.append(kv)
-            h = layer_norm(x, w, p + "cross_attn_ln")
-            q = _split(linear(h, w, p + "cross_attn.query"), dims.n_text_head)
-            o = linear(_merge(attention(q, cross[i][0], cross[i][1])), w, p + "cross_attn.out")
+            h = self.r(layer_norm(x, w, p + "cross_attn_ln"))
+            q = linear(h, w, p + "cross_attn.query")
+            if b * s > 256:                 # the engine's large-row path stores the query in bf16
+                q = self.r(q)
+            q = _split(q, dims.n_text_head)
+            o = linear(self.r(_merge(attention(q, cross[i][0], cross[i][1]))), w, p + "cross_attn.out")
             x = x + o
             x = self._mlp_block(x, p)
-        x = layer_norm(x, w, "decoder.ln")
+        x = self.r(layer_norm(x, w, "decoder.ln"))
         return x @ w["decoder.token_embedding.weight"].T, new_cache
 
 

@@ -10,6 +10,7 @@ def run(name, dims, B, seed, style):
     w = P.bf16_round(om.random_weights(dims, seed=seed, style=style))
     eng = WhisperEngine(P.dims_dict(dims), w, max_batch=B, max_beams=1, max_text_len=40, max_prompt_len=24)
     o = om.Whisper(dims, w)
+    ob = om.Whisper(dims, w, round_acts=True)
     g = torch.Generator().manual_seed(1)
     mel = torch.rand(B, 3000, dims.n_mels, generator=g) * 2 - 1
     with torch.no_grad():
@@ -20,7 +21,10 @@ def run(name, dims, B, seed, style):
     with torch.no_grad():
         ref, _ = o.decoder(torch.from_numpy(toks).long(), o.cross_kv(enc))
         ref2, _ = o.decoder(torch.from_numpy(toks).long(), o.cross_kv(got_enc))
-    for tag, r in (("oracle-enc", ref), ("engine-enc", ref2)):
+        encb = ob.encoder(mel)
+        ref3, _ = ob.decoder(torch.from_numpy(toks).long(), ob.cross_kv(encb))
+    print("   bf16-emulating oracle: enc relL2 %.2e (fp32 oracle vs it %.2e)" % (P.rel_l2(got_enc.numpy(), encb.numpy()), P.rel_l2(encb.numpy(), enc.numpy())))
+    for tag, r in (("oracle-enc", ref), ("bf16-emul", ref3)):
         lg, lr = torch.log_softmax(got, -1), torch.log_softmax(r, -1)
         top = lr.topk(5, -1).indices
         d = (lg.gather(-1, top) - lr.gather(-1, top))

@@ -16,6 +16,8 @@ windows with the same torch CPU generator and only the expensive oracle outputs 
     margins                 log-prob gap between the oracle's best and second-best token per step
                             (a gap below the test's near-tie allowance marks a step where a bf16
                             engine may legitimately pick the runner-up)
+    logit_std               standard deviation of the oracle's logits row per step (the near-tie
+                            allowance is stated relative to it, tests/_parity.py)
 
 The reference holds no fixture for this part of the path (parity unpinned, see the oracle's
 header); these files pin the HIP path to the oracle, not the oracle to the reference.
@@ -78,7 +80,7 @@ def make(name):
         enc_mean=enc.mean(dim=(1, 2)).numpy().astype(np.float32),
         enc_std=enc.std(dim=(1, 2)).numpy().astype(np.float32),
         tokens=out["tokens"].numpy().astype(np.int32), scores=out["scores"].numpy().astype(np.float32),
-        margins=margins)
+        margins=margins, logit_std=out["logits"].std(dim=-1).numpy().astype(np.float32))
     print("%s: done in %.1f s, %d steps with a margin < 0.05" % (name, time.time() - t0,
                                                                  int((margins < 0.05).sum())), flush=True)
 

@@ -284,12 +284,12 @@ def test_greedy_sampling(small):
                 best = int(key.argmax())
                 total += 1
                 exact += best == tokens[i, t]
-                assert float(key[best] - key[tokens[i, t]]) < 0.05, (i, t)
+                assert float(key[best] - key[tokens[i, t]]) < P.row_margin(logits[i, -1]), (i, t)
                 want_score[i] += float(lp[i, tokens[i, t]])
             lengths_t = lengths_t + 1
             inputs = gen[:, t][:, None]
     assert exact >= total - 3
-    assert np.abs(want_score - scores).max() < 0.05 * 16
+    assert np.abs(want_score - scores).max() < 0.02 * 3.5 * 16
 
 
 def test_beam_sampling(small):
@@ -313,8 +313,8 @@ def test_beam_sampling(small):
         for b in range(3):
             for d in range(nb):
                 key = lp0[b] + om.gumbel_noise(77, 0 * 3 * nb + b * nb + d, v)
-                assert float(key.max() - key[one[b, d, 0]]) < 0.05
-                assert abs(float(lp0[b, one[b, d, 0]]) - s1[b, d]) < 0.05
+                assert float(key.max() - key[one[b, d, 0]]) < P.row_margin(logits[b, -1])
+                assert abs(float(lp0[b, one[b, d, 0]]) - s1[b, d]) < P.row_margin(logits[b, -1])
         # second step: the parents are the first step's draws (same seed, same streams)
         for b in range(3):
             full = torch.cat([p[b:b + 1].repeat(nb, 1), torch.from_numpy(one[b]).long()], dim=1)
@@ -328,8 +328,8 @@ def test_beam_sampling(small):
                 parents = [q for q in range(nb) if int(one[b, q, 0]) == t0]
                 assert parents, "the second-step sequence must extend one of the first-step draws"
                 got = max(float(key[q * v + t1]) for q in parents)
-                assert float(key.max()) - got < 0.05
-                assert abs(max(float(lws[q * v + t1]) for q in parents) - s2[b, d]) < 0.1
+                assert float(key.max()) - got < P.row_margin(logits[:, -1])
+                assert abs(max(float(lws[q * v + t1]) for q in parents) - s2[b, d]) < 2 * P.row_margin(logits[:, -1])
 
 
 def test_suppress_list_matches_oracle(small):
@@ -382,19 +382,18 @@ def test_beam_search_finished_beams(small):
         assert scores[b, 0] >= scores[b, 1] - 1e-4
     # early stopping (generation_utils.py:326-330): the state returned is the one of the first step
     # after which the first `num_sentences` beams of every window are finished, whatever the
-    # engine's host-side polling interval.  All but four tokens are banned so that every window
-    # gets there within a few steps.
-    survivors = {7, 123, 500, 998}
-    banned = [i for i in range(dims.n_vocab) if i not in survivors]
-    kw = dict(method="beam", num_beams=4, num_sentences=2, eos_token=998, pad_token=0, logits_filter=banned)
+    # engine's host-side polling interval.  One window, EOS = the third token of its best beam.
+    engine.encode(mel[:1])
+    one = prompt[:1]
+    kw = dict(method="beam", num_beams=4, num_sentences=2, eos_token=int(free[0, 0, 2]), pad_token=0)
     stop = None
     for t in range(1, 17):
-        ft, fl, fs = engine.generate(prompt, max_new_tokens=t, early_stopping=False, **kw)
-        if (ft == 998).any(axis=2).all():
+        ft, fl, fs = engine.generate(one, max_new_tokens=t, early_stopping=False, **kw)
+        if (ft == kw["eos_token"]).any(axis=2).all():
             stop = t
             break
-    assert stop is not None and stop < 16, "no step at which every window's two best beams are finished"
+    assert stop is not None and 1 < stop < 16, "no step at which the window's two best beams are finished"
     for check_every in (1, 8):
-        et, el, es = engine.generate(prompt, max_new_tokens=16, early_stopping=True, check_every=check_every, **kw)
+        et, el, es = engine.generate(one, max_new_tokens=16, early_stopping=True, check_every=check_every, **kw)
         assert np.array_equal(et[:, :, :stop], ft) and (et[:, :, stop:] == 0).all()
         assert np.array_equal(el, fl) and np.allclose(es, fs, atol=1e-5)
