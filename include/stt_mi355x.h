@@ -61,6 +61,17 @@ size_t stt_logmel_workspace_bytes(int64_t n_samples);
 int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,
                    float* d_mel, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* stt_logmel_run without the workspace argument and without any allocation, for callers that
+ * cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid it).  No counterpart in the reference.  The workspace is a 64 KiB array inside the
+ * library's code object (one copy per GPU, held until the process ends), which limits the clip
+ * to stt_logmel_static_max_samples() samples (about 2.6 h at 16 kHz); longer clips get
+ * STT_ERR_WORKSPACE.  The plan must have been created on the current device.  All calls on one
+ * GPU share that array: calls that overlap on one GPU race (also across plans and streams). */
+int64_t stt_logmel_static_max_samples(void);
+int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,
+                          float* d_mel, void* stream);
+
 /* The two halves of stt_logmel_run, for a clip whose frames are computed in several
  * pieces (for instance on several GPUs) and share one clip-wide maximum:
  *  stage1 computes frames [frame_begin, frame_begin + frame_count) of a clip of

@@ -30,6 +30,8 @@ def _declare(lib):
         "stt_logmel_num_frames": (i64, [i64]),
         "stt_logmel_workspace_bytes": (sz, [i64]),
         "stt_logmel_run": (i32, [vp, vp, i64, vp, vp, sz, vp]),
+        "stt_logmel_static_max_samples": (i64, []),
+        "stt_logmel_run_static": (i32, [vp, vp, i64, vp, vp]),
         "stt_logmel_stage1": (i32, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, sz, vp]),
         "stt_logmel_stage2": (i32, [vp, vp, i64, vp, vp, vp]),
     }

@@ -410,7 +410,16 @@ struct stt_logmel_plan {
   int n_cu;
   float* d_table;
   unsigned* d_sync;      // [0] ticket counter, [64..] one float per block; zeroed at creation
+  void* d_static_ws;     // this device's copy of lm_static_ws (address looked up at creation)
 };
+
+// Workspace of stt_logmel_run_static: the same bytes stt_logmel_run takes as `d_workspace`
+// (piece maximum, per-segment minima, padded copy of a short clip), held in the code object so
+// that the call needs no allocation.  Every GPU the library runs on holds its own copy at its
+// own address; host code reaches it only through the pointer hipGetSymbolAddress returned for
+// the current device (the array's name is a host-side stand-in, not a device address).
+#define LM_STATIC_WS_BYTES 65536
+static __device__ __align__(256) unsigned char lm_static_ws[LM_STATIC_WS_BYTES];
 
 static const size_t kWsHeader = 256;      // piece maximum lives in the first float
 static const size_t kWsPadPcm = 512 * sizeof(float);
@@ -478,6 +487,9 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
                             hipMemcpyHostToDevice), ((void)hipFree(p->d_table), delete p));
   STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4), ((void)hipFree(p->d_table), delete p));
   STT_HIP_OR_FAIL(hipMemset(p->d_sync, 0, (64 + 1024) * 4),
+                  ((void)hipFree(p->d_sync), (void)hipFree(p->d_table), delete p));
+  // the plan belongs to the current device: look up that device's copy of the static workspace
+  STT_HIP_OR_FAIL(hipGetSymbolAddress(&p->d_static_ws, HIP_SYMBOL(lm_static_ws)),
                   ((void)hipFree(p->d_sync), (void)hipFree(p->d_table), delete p));
   *plan = p;
   return STT_OK;
@@ -592,6 +604,33 @@ int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_sa
                              workspace_bytes, stream);
   if (rc != STT_OK) return rc;
   return stt_logmel_stage2(plan, d_mel, frames, piece_max, d_workspace, stream);
+}
+
+int64_t stt_logmel_static_max_samples(void) {
+  // largest n with stt_logmel_workspace_bytes(n) <= LM_STATIC_WS_BYTES
+  const int64_t tiles = (int64_t)(LM_STATIC_WS_BYTES - kWsHeader - kWsPadPcm) / (4 * sizeof(float)) / 64 * 64;
+  return tiles * LM_TILE_FRAMES * LM_HOP;
+}
+
+int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,
+                          float* d_mel, void* stream) {
+  if (!plan || !d_pcm || !d_mel) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_samples <= 0) return stt_fail(STT_ERR_INVALID_ARGUMENT, "empty clip");
+  if (n_samples > stt_logmel_static_max_samples())
+    return stt_fail(STT_ERR_WORKSPACE,
+                    "clip of %lld samples exceeds the %lld samples the static workspace (%d bytes) "
+                    "serves: use stt_logmel_run with a caller workspace",
+                    (long long)n_samples, (long long)stt_logmel_static_max_samples(), LM_STATIC_WS_BYTES);
+  int dev = -1;
+  STT_HIP_OR_FAIL(hipGetDevice(&dev), (void)0);
+  if (dev != plan->device)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "plan was created on device %d, current device is %d",
+                    plan->device, dev);
+  // Nothing in the workspace has to start at zero: the piece maximum and every segment minimum
+  // the second kernel reads are written by the first kernel of the same call, and the padded
+  // copy of a short clip is cleared by the call that uses it.
+  return stt_logmel_run(plan, d_pcm, n_samples, d_mel, plan->d_static_ws,
+                        stt_logmel_workspace_bytes(n_samples), stream);
 }
 
 }  // extern "C"
