@@ -6,10 +6,10 @@ import torch
 
 def run():
     from oracle import model as om
-    from .engine import WhisperEngine
+    from speech_to_text_amd.engine import WhisperEngine
     dims = om.Dims(n_mels=80, n_audio_ctx=1500, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
                    n_vocab=1000, n_text_ctx=64, n_text_state=128, n_text_head=2, n_text_layer=2)
-    w = {k: v.to(torch.bfloat16).float() for k, v in om.random_weights(dims, seed=0).items()}
+    w = {k: v.to(torch.bfloat16).float() for k, v in om.random_weights(dims, seed=0, style="peaked").items()}
     keys = ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer", "n_vocab",
             "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")
     eng = WhisperEngine({k: getattr(dims, k) for k in keys}, w, max_batch=2, max_beams=1,
@@ -28,5 +28,6 @@ def run():
         lp = torch.log_softmax(logits[:, 2:], dim=-1)
         best = lp.max(dim=-1).values
         mine = lp.gather(2, torch.from_numpy(toks).long()[:, :, None])[:, :, 0]
-        assert float((best - mine).max()) < 0.05, "greedy tokens are not the oracle's argmax"
+        # near-tie allowance: 0.04 x the standard deviation of the logits row
+        assert bool(((best - mine) <= 0.04 * logits[:, 2:].std(dim=-1)).all()), "greedy tokens are not the oracle's argmax"
     print("smoke ok: encoder rel L2 %.2e, %d greedy tokens agree with the oracle" % (rel, toks.size))

@@ -4,70 +4,83 @@ O(samples) numpy passes over the whole clip and stay on the host, before any sha
 
 Follows utils/audio/audio_processing.py:48-60 (normalize_audio) and :98-198 (trim_silence_rms).
 """
-import itertools
-
 import numpy as np
 
 
 def normalize_audio(audio, max_val=32767, dtype=np.int16):
-    if max_val <= 1.:
-        dtype = np.float32
-    audio = audio - np.mean(audio)
-    peak = np.max(np.abs(audio))
-    if peak <= 1e-9:
-        return audio.astype(dtype)
-    return (audio * (max_val / peak)).astype(dtype)
+    """Zero mean, peak scaled to `max_val`; a float result when max_val <= 1 (what Whisper asks)."""
+    out_type = np.float32 if max_val <= 1. else dtype
+    centred = np.asarray(audio) - np.mean(audio)
+    peak = float(np.abs(centred).max()) if centred.size else 0.
+    gain = max_val / peak if peak > 1e-9 else 1.
+    return (centred * gain).astype(out_type) if gain != 1. else centred.astype(out_type)
+
+
+def _silence_intervals(audio, rate, threshold, min_silence, block_size, min_voice_time):
+    """Silent stretches of `audio` as two float64 arrays (start, end) in seconds.
+
+    A block of `block_size` samples is silent when its peak magnitude is below the threshold
+    (dB re full scale); runs of silent blocks shorter than `min_silence` do not count, and two
+    stretches separated by less than `min_voice_time` of sound are joined.  Times are kept as
+    block index x block duration in float64 and only the caller converts them to samples, so
+    that the truncations land where the reference's do."""
+    block_time = block_size / rate
+    x = np.asarray(audio)
+    if not np.issubdtype(x.dtype, np.floating):
+        x = x / np.iinfo(x.dtype).max
+    n_blocks = -(-len(x) // block_size)
+    padded = np.zeros(n_blocks * block_size, dtype=x.dtype)
+    padded[: len(x)] = x
+    peak_sq = (padded.reshape(n_blocks, block_size) ** 2).max(axis=1)
+    silent = np.sqrt(peak_sq) < 10 ** (threshold / 20.0)
+
+    # run lengths: a run starts wherever the flag differs from the block before
+    first = np.flatnonzero(np.r_[True, silent[1:] != silent[:-1]])
+    length = np.diff(np.r_[first, n_blocks])
+    keep = silent[first] & (length * block_time >= min_silence)
+    start = first[keep] * block_time
+    end = np.minimum(len(x) / rate, (first[keep] + length[keep]) * block_time)
+    if min_voice_time and len(start) > 1:
+        # a stretch opens a new group unless less than min_voice_time of sound precedes it
+        opens = np.r_[True, (start[1:] - end[:-1]) >= min_voice_time]
+        closes = np.r_[opens[1:], True]
+        start, end = start[opens], end[closes]
+    return start, end
 
 
 def trim_silence_rms(audio, *, rate, mode='start_end', threshold=-25, min_silence=0.1,
                      block_size=0.01, replace_by=0.5, min_voice_time=0.2, **kwargs):
-    if isinstance(replace_by, float): replace_by = int(replace_by * rate)
-    if isinstance(block_size, float): block_size = int(block_size * rate)
-    block_time = block_size / rate
-    amplitude_threshold = 10 ** (threshold / 20.0)
+    """`mode='remove'`: every silent stretch is cut down to `replace_by` seconds (all of it at the
+    head and tail of the clip, half on either side inside); 'start' / 'end' / 'start_end' only trim
+    the ends.  Same results as utils/audio/audio_processing.py:98-198 of the reference."""
+    if isinstance(replace_by, float):
+        replace_by = int(replace_by * rate)
+    if isinstance(block_size, float):
+        block_size = int(block_size * rate)
+    n = len(audio)
+    start_t, end_t = _silence_intervals(audio, rate, threshold, min_silence, block_size, min_voice_time)
+    lo = (start_t * rate).astype(np.int64)          # truncation, like int()
+    hi = (end_t * rate).astype(np.int64)
+    at_head = lo == 0
+    at_tail = (np.abs(hi - n) <= 1) & ~at_head
 
-    blocks = audio
-    if not np.issubdtype(blocks.dtype, np.floating):
-        blocks = blocks / np.iinfo(blocks.dtype).max
-    pad = len(blocks) % block_size
-    if pad != 0:
-        blocks = np.pad(blocks, [(0, block_size - pad)])
-    blocks = blocks.reshape(-1, block_size)
-    silent = np.sqrt(np.max(blocks ** 2, axis=1)) < amplitude_threshold
+    if mode != 'remove':
+        if 'end' in mode and len(lo) and abs(end_t[-1] * rate - n) <= 1:
+            audio = audio[: lo[-1] + replace_by]
+        if 'start' in mode and len(lo) and start_t[0] == 0:
+            audio = audio[max(0, hi[0] - replace_by):]
+        return audio
 
-    # run-length groups of silent blocks that last at least `min_silence`
-    starts, ends, idx = [], [], 0
-    for is_silent, group in itertools.groupby(silent):
-        n = sum(1 for _ in group)
-        if is_silent and n * block_time >= min_silence:
-            starts.append(idx * block_time)
-            ends.append(min(len(audio) / rate, (idx + n) * block_time))
-        idx += n
-    if min_voice_time:
-        for i in reversed(range(len(starts) - 1)):
-            if starts[i + 1] - ends[i] < min_voice_time:
-                starts.pop(i + 1)
-                ends.pop(i)
-
-    if mode == 'remove':
-        half = replace_by // 2
-        drop = np.zeros((len(audio),), dtype=bool)
-        for start, end in zip(starts, ends):
-            start, end = int(start * rate), int(end * rate)
-            if start == 0:
-                drop[: max(0, end - replace_by)] = True
-            elif abs(end - len(audio)) <= 1:
-                drop[start + replace_by:] = True
-            else:
-                start, end = start + half, end - half
-                if start < end:
-                    drop[start: end] = True
-        return audio[~drop]
-    if 'end' in mode and starts and abs(ends[-1] * rate - len(audio)) <= 1:
-        audio = audio[: int(starts[-1] * rate) + replace_by]
-    if 'start' in mode and starts and starts[0] == 0:
-        audio = audio[max(0, int(ends[0] * rate) - replace_by):]
-    return audio
+    half = replace_by // 2
+    cut_lo = np.where(at_head, 0, np.where(at_tail, lo + replace_by, lo + half))
+    cut_hi = np.where(at_head, hi - replace_by, np.where(at_tail, n, hi - half))
+    cut_lo, cut_hi = np.clip(cut_lo, 0, n), np.clip(cut_hi, 0, n)
+    ok = cut_lo < cut_hi
+    # +1 / -1 at the borders of every cut, summed up: > 0 inside any cut
+    delta = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(delta, cut_lo[ok], 1)
+    np.add.at(delta, cut_hi[ok], -1)
+    return audio[np.cumsum(delta[:-1]) == 0]
 
 
 # what Whisper ends up with in `trim_kwargs` (models/interfaces/base_audio_model.py:20-28, 121-132)

@@ -183,70 +183,78 @@ class Whisper(object):
         probs = torch.softmax(pred[0, -1, :][idx], dim=-1).cpu().numpy()
         return self.languages[int(np.argmax(probs))], {l: float(p) for l, p in zip(self.languages, probs)}
 
-    # ---- sequential long-form decoding (whisper.py:204-331)
+    # ---- sequential long-form decoding (behaviour of whisper.py:204-331)
+    def _prompt_for(self, lang, history, max_length, **kwargs):
+        """[<|startofprev|>, last max_length // 2 - 1 tokens of `history`] + the task prompt."""
+        task = self.get_inference_tokens(lang=lang, **kwargs)
+        if not history:
+            return np.asarray(task, dtype=np.int32)
+        tail = history[-(max_length // 2 - 1):]
+        return np.asarray([self.start_of_prev_token_idx] + list(tail) + task, dtype=np.int32)
+
+    def _decode_window(self, window, prompt, **kwargs):
+        """One 30 s window through the runtime -> generated ids of the best sentence (no prompt, no EOS)."""
+        out = self.compiled_infer(window[None], tokens=prompt[None], tokens_length=len(prompt), **kwargs)
+        ids = process_model_output(out)[0] if hasattr(out, 'tokens') else out[0]
+        while len(ids) and isinstance(ids[0], (list, np.ndarray)):      # [beam][token] -> best beam
+            ids = ids[0]
+        return np.asarray(ids, dtype=np.int32)
+
+    def _split_at_timestamps(self, ids, offset_s, window_s, lang):
+        """Segments of one window's ids, the number of mel frames they account for (None: the whole
+        window) and how many leading ids join the history for the next prompt.
+
+        Two timestamp tokens in a row close one segment and open the next, so the ids are cut
+        after the first of every such pair; every piece then reads <start> text ... <end>.  What
+        follows the last pair is dropped and decoded again: the next window starts at the last
+        closed timestamp.  Without any pair the window is one segment that lasts until its last
+        timestamp (if any, and not the zero one) or the end of the window."""
+        t0, step = self.timestamp_begin_idx, self.time_precision
+        stamp = ids >= t0
+        pairs = np.flatnonzero(stamp[1:] & stamp[:-1]) + 1
+        if pairs.size == 0:
+            text = ids[ids < self.eos_token_idx]
+            marks = ids[stamp]
+            length_s = window_s if not (marks.size and marks[-1] != t0) else float(marks[-1] - t0) * step
+            seg = {'start': offset_s, 'end': offset_s + length_s, 'text': self.decode_output(text),
+                   'tokens': text, 'lang': lang}
+            return [seg], None, text.tolist()
+        segments = []
+        for piece in np.split(ids[: pairs[-1]], pairs[:-1]):
+            body = piece[1:-1]
+            segments.append({'start': offset_s + (piece[0] - t0) * step, 'end': offset_s + (piece[-1] - t0) * step,
+                             'text': self.decode_output(body), 'tokens': body[body < self.eos_token_idx],
+                             'lang': lang})
+        closed_at = int(ids[pairs[-1] - 1] - t0)
+        return segments, closed_at * 2, ids[: pairs[-1] + 1].tolist()      # 2 mel frames per timestamp unit
+
     def _infer_segments(self, mel, *, lang=None, verbose=True, force_detect_language=False,
                         condition_on_previous_text=True, segment_processing=None, **kwargs):
         kwargs['encoder_output_lengths'] = 1500
-        kwargs.setdefault('max_length', self.max_output_length)
-        seek = kwargs.pop('seek', 0)
-        n_frames = len(mel)
-        input_stride = 2
-        all_tokens, segments = [], []
-        while seek < n_frames:
-            segment = mel[seek: seek + self.max_input_length]
-            segment_length = len(segment)
-            segment = self.pad_or_trim(segment)
+        max_length = kwargs.setdefault('max_length', self.max_output_length)
+        seek, total = kwargs.pop('seek', 0), len(mel)
+        history, segments = [], []
+        while seek < total:
+            valid = min(self.max_input_length, total - seek)
+            window = self.pad_or_trim(mel[seek: seek + valid])
             if lang is None and force_detect_language:
-                lang, _ = self.detect_language(segment)
-            tokens = self.get_inference_tokens(lang=lang, **kwargs)
-            if condition_on_previous_text and len(all_tokens):
-                tokens = np.array([self.start_of_prev_token_idx] +
-                                  all_tokens[-(kwargs['max_length'] // 2 - 1):] + tokens, 'int32')
-            else:
-                tokens = np.array(tokens, 'int32')
-            out = self.compiled_infer(segment[None], tokens=tokens[None], tokens_length=len(tokens), **kwargs)
-            tokens = process_model_output(out)[0] if hasattr(out, 'tokens') else out[0]
-            if len(tokens) and isinstance(tokens[0], (list, np.ndarray)):
-                tokens = tokens[0]
-            tokens = np.array(tokens, dtype=np.int32)
-            if lang is None:
-                lang = self.vocabulary.idx_to_lang.get(int(tokens[0]), None) if len(tokens) else None
-                tokens = tokens[2:]
-            timestamp_offset = self._get_sample_time(seek)
-            ts = tokens >= self.timestamp_begin_idx
-            consecutive = np.where(np.logical_and(ts[:-1], ts[1:]))[0] + 1
-            if len(consecutive) > 0:
-                last_slice = 0
-                for current_slice in consecutive:
-                    sliced = tokens[last_slice: current_slice]
-                    start_pos = sliced[0] - self.timestamp_begin_idx
-                    end_pos = sliced[-1] - self.timestamp_begin_idx
-                    sliced = sliced[1:-1]
-                    segments.append({
-                        'start': timestamp_offset + start_pos * self.time_precision,
-                        'end': timestamp_offset + end_pos * self.time_precision,
-                        'text': self.decode_output(sliced),
-                        'tokens': sliced[sliced < self.eos_token_idx], 'lang': lang})
-                    if segment_processing is not None:
-                        segment_processing(segments[-1], segment=segment)
-                    last_slice = current_slice
-                last_pos = tokens[last_slice - 1] - self.timestamp_begin_idx
-                seek += int(last_pos) * input_stride
-                all_tokens.extend(tokens[: last_slice + 1].tolist())
-            else:
-                duration = self._get_sample_time(segment_length)
-                stamps = tokens[ts]
-                if len(stamps) > 0 and stamps[-1] != self.timestamp_begin_idx:
-                    duration = float(stamps[-1] - self.timestamp_begin_idx) * self.time_precision
-                tokens = tokens[tokens < self.eos_token_idx]
-                segments.append({'start': timestamp_offset, 'end': timestamp_offset + duration,
-                                 'text': self.decode_output(tokens), 'tokens': tokens, 'lang': lang})
+                lang, _ = self.detect_language(window)
+            prompt = self._prompt_for(lang, history if condition_on_previous_text else (), **kwargs)
+            ids = self._decode_window(window, prompt, **kwargs)
+            if lang is None:                 # prompt was <|sot|> alone: the model wrote language and task
+                lang = self.vocabulary.idx_to_lang.get(int(ids[0])) if len(ids) else None
+                ids = ids[2:]
+            new, frames, kept = self._split_at_timestamps(ids, self._get_sample_time(seek),
+                                                          self._get_sample_time(valid), lang)
+            for seg in new:
+                seg['time'] = seg['end'] - seg['start']
                 if segment_processing is not None:
-                    segment_processing(segments[-1], segment=segment)
-                seek += self.max_input_length if segment_length >= self.max_input_length else segment_length
-                all_tokens.extend(tokens.tolist())
-        for seg in segments:
-            seg['time'] = seg['end'] - seg['start']
+                    segment_processing(seg, segment=window)
+            segments += new
+            history += kept
+            # a pair closed at 0.00 s would leave `seek` where it is for ever (the reference's loop,
+            # whisper.py:296-299, does not terminate on such an output): move on by the whole window
+            seek += valid if not frames else frames
         return segments
 
     # ---- independent windows, batched (and shardable across GPUs)

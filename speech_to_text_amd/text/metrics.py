@@ -1,58 +1,83 @@
-"""Weighted Levenshtein distance with partial alignment: the building block of the README's
-keyword ``search`` (utils/text/metrics.py:85-159).  Host code: the strings are a few hundred
-symbols long."""
+"""Weighted Levenshtein distance with partial alignment - the building block of the README's
+keyword ``search`` - and the unpacking of a generation result into token lists.
+
+Same signatures and results as the reference's `edit_distance` (utils/text/metrics.py:85-159)
+and `process_model_output` (utils/text/tokens_processing.py:20-39).  Host code: the strings are
+a few hundred symbols long.
+"""
 import numpy as np
 
 
-def _normalize(data):
-    if isinstance(data, np.ndarray): data = data.tolist()
-    if isinstance(data, bytes): data = data.decode()
-    if isinstance(data, (list, tuple)) and len(data) and isinstance(data[0], (int, np.integer)):
-        data = ' '.join(str(d) for d in data)
+def _as_symbols(data):
+    """bytes -> str, int sequences -> the string of their decimal forms joined by blanks (what the
+    reference's dispatcher does before the distance, metrics.py:243-249)."""
+    if isinstance(data, np.ndarray):
+        data = data.tolist()
+    if isinstance(data, bytes):
+        data = data.decode()
+    if isinstance(data, (list, tuple)) and data and isinstance(data[0], (int, np.integer)):
+        data = " ".join(map(str, data))
     return data
 
 
 def edit_distance(hypothesis, truth, partial=False, deletion_cost={}, insertion_cost={},
                   replacement_cost={}, default_del_cost=1, default_insert_cost=1,
                   default_replace_cost=1, normalize=True, return_matrix=False, **kwargs):
-    hypothesis, truth = _normalize(hypothesis), _normalize(truth)
-    n, m = len(hypothesis), len(truth)
-    matrix = np.zeros((n + 1, m + 1))
-    del_costs = np.array([0] + [deletion_cost.get(h, default_del_cost) for h in hypothesis])
-    ins_costs = np.array([insertion_cost.get(t, default_insert_cost) for t in truth])
-    matrix[:, 0] = np.cumsum(del_costs)
+    """D[i, j] = cost of turning hypothesis[:i] into truth[:j]; with `partial` the first row is
+    free (the hypothesis may start anywhere in `truth`) and the result is the minimum of the last
+    row (it may end anywhere).  Normalised by len(truth), or len(hypothesis) when `partial`.
+
+    A row is filled without a Python loop over columns: with c[j] the cost of inserting truth[:j]
+    and v[j] the best of "delete" / "match or replace" for column j (v[0] = D[i, 0]), the insert
+    recurrence D[i, j] = min(v[j], D[i, j-1] + ins[j-1]) unrolls to
+    D[i, j] = c[j] + min_{k <= j} (v[k] - c[k]), a running minimum.  (Exact for costs that are
+    sums of powers of two, such as the defaults; other costs agree to rounding.)"""
+    hyp, ref = _as_symbols(hypothesis), _as_symbols(truth)
+    rows, cols = len(hyp), len(ref)
+    ref_symbols = np.array(list(ref)) if isinstance(ref, str) else np.asarray(ref)
+    ins_prefix = np.concatenate([[0.], np.cumsum([insertion_cost.get(t, default_insert_cost) for t in ref],
+                                                  dtype=np.float64)])
+    table = np.zeros((rows + 1, cols + 1))
     if not partial:
-        matrix[0, 1:] = np.cumsum(ins_costs)
-    truth_arr = np.array(list(truth)) if isinstance(truth, str) else np.asarray(truth)
-    for i in range(1, n + 1):
-        h = hypothesis[i - 1]
-        sub = np.array([replacement_cost.get(h, {}).get(t, default_replace_cost) for t in truth])
-        diag = matrix[i - 1, :-1] + sub * (truth_arr != h)
-        up = matrix[i - 1, 1:] + del_costs[i]
-        best = np.minimum(up, diag)
-        row = matrix[i]
-        for j in range(1, m + 1):
-            left = row[j - 1] + ins_costs[j - 1]
-            row[j] = best[j - 1] if best[j - 1] < left else left
-    distance = matrix[-1, -1] if not partial else np.min(matrix[-1, 1:])
+        table[0] = ins_prefix
+    for i, symbol in enumerate(hyp, start=1):
+        above = table[i - 1]
+        swap = replacement_cost.get(symbol, {})
+        change = np.fromiter((swap.get(t, default_replace_cost) for t in ref), dtype=np.float64, count=cols)
+        change[ref_symbols == symbol] = 0.
+        drop = deletion_cost.get(symbol, default_del_cost)
+        candidates = np.empty(cols + 1)
+        candidates[0] = above[0] + drop
+        np.minimum(above[1:] + drop, above[:-1] + change, out=candidates[1:])
+        table[i] = np.minimum.accumulate(candidates - ins_prefix) + ins_prefix
+    distance = table[-1, 1:].min() if partial else table[-1, -1]
     if normalize:
-        distance = distance / m if not partial else distance / n
-    return distance if not return_matrix else (distance, matrix)
+        distance = distance / (rows if partial else cols)
+    return (distance, table) if return_matrix else distance
 
 
 def process_model_output(output, offset=None, lengths=None):
-    """tokens[b][(beam)][offset : length] as arrays (utils/text/tokens_processing.py:20-39)."""
-    if hasattr(output, 'lengths') or hasattr(output, 'offset'):
-        lengths = np.asarray(output.lengths)
-        if not hasattr(output, 'offset'):
-            offset = np.zeros_like(lengths)
-        else:
-            offset = np.asarray(output.offset)
-            if lengths.ndim == 2 and offset.ndim == 1:
-                offset = np.tile(offset[:, None], [1, lengths.shape[1]])
-        output = output.tokens
-    elif lengths is None:
-        return output.tokens
-    if lengths.ndim:
-        return [process_model_output(out, off, length) for out, off, length in zip(output, offset, lengths)]
-    return np.asarray(output[int(offset): int(lengths)])
+    """Token ids without prompt and padding: `tokens[...][offset : length]` for every leading index
+    of `lengths`, as nested lists of arrays (one level per dimension of `lengths`: batch, then
+    beams).  `output` is an object with `tokens` / `lengths` (/ `offset`) or the token array
+    itself; without lengths the tokens come back untouched."""
+    tokens = getattr(output, "tokens", output)
+    if lengths is None:
+        lengths = getattr(output, "lengths", None)
+    if lengths is None:
+        return tokens
+    if offset is None:
+        offset = getattr(output, "offset", None)
+    lengths = np.asarray(lengths)
+    if offset is None:
+        first = np.zeros(lengths.shape, dtype=np.int64)
+    else:
+        first = np.asarray(offset)
+        first = np.broadcast_to(first.reshape(first.shape + (1,) * (lengths.ndim - first.ndim)), lengths.shape)
+
+    def unpack(prefix, depth):
+        if depth == lengths.ndim:
+            return np.asarray(tokens[prefix][int(first[prefix]): int(lengths[prefix])])
+        return [unpack(prefix + (k,), depth + 1) for k in range(lengths.shape[depth])]
+
+    return unpack((), 0)

@@ -37,9 +37,27 @@ def test_infer_audio_file_matches_notebook_geometry(model, golden_dir):
 
 
 def test_detect_language(model, golden_dir):
-    lang, probs = model.detect_language(os.path.join(golden_dir, "audio_test.wav"))
+    """Language probabilities (whisper.py:174-202) against the oracle: its float32 model on the same
+    bf16-rounded weights and the same mel, one decoder step on <|sot|>, softmax over the 99
+    language logits."""
+    from oracle import model as om
+    from oracle import segments as osg
+    from speech_to_text_amd.weights import random_whisper_weights
+    wav = os.path.join(golden_dir, "audio_test.wav")
+    lang, probs = model.detect_language(wav)
     assert lang in model.languages and len(probs) == 99
     assert abs(sum(probs.values()) - 1.0) < 1e-3
+    dims = om.Dims.named("tiny")
+    w = {k: v.to(torch.bfloat16).float() for k, v in random_whisper_weights(model.model.dims, 0).items()}
+    oracle = om.Whisper(dims, w)
+    mel = model.get_input(wav, pad_or_trim=True).cpu()[None]
+    with torch.no_grad():
+        logits, _ = oracle.decoder(torch.tensor([[model.sos_token_idx]]), oracle.cross_kv(oracle.encoder(mel)))
+    want_lang, want = osg.detect_language(logits[0, -1].numpy(), model.language_indexes, model.languages)
+    diff = max(abs(probs[k] - want[k]) for k in want)
+    assert diff < 0.02 * max(want.values()) + 1e-4, diff
+    ranked = sorted(want.values())
+    assert lang == want_lang or ranked[-1] - ranked[-2] < 0.02 * ranked[-1]
 
 
 def test_window_batching_is_batch_invariant(model):
@@ -122,14 +140,53 @@ def test_sequential_long_form_with_previous_text(model):
     assert abs(res["segments"][-1]["end"] - 65.0) < 1e-9
 
 
-def test_timestamp_mode_and_search(model):
+def _recorded(model, calls):
+    """The runtime with every call's (prompt, generated ids) appended to `calls`."""
+    from speech_to_text_amd.text.metrics import process_model_output
+    inner = model.model
+
+    class Recorder(object):
+        def __getattr__(self, name):
+            return getattr(inner, name)
+
+        def __call__(self, mel, **kw):
+            out = inner(mel, **kw)
+            ids = process_model_output(out)[0]
+            while len(ids) and isinstance(ids[0], (list, np.ndarray)):
+                ids = ids[0]
+            calls.append((np.asarray(kw["tokens"])[0, : kw["tokens_length"]].tolist(), np.asarray(ids).tolist()))
+            return out
+    return Recorder()
+
+
+@pytest.mark.parametrize("seconds,conditioned", [(12, True), (71, True), (71, False)])
+def test_timestamp_mode_and_search(model, seconds, conditioned):
+    """Sequential long-form decoding with the timestamp rules on the real engine: the wrapper's
+    segments, seeks and prompts equal the oracle's restatement of the reference's loop
+    (oracle/segments.py) replayed on the ids the engine produced."""
+    from oracle import segments as osg
     rng = np.random.default_rng(5)
-    audio = rng.uniform(-1, 1, 16000 * 12).astype(np.float32)
-    res = model.infer(audio, lang="en", max_length=48, normalize=False, trim_silence=False,
-                      logits_filter=model.logits_filter)
-    assert len(res["segments"]) >= 1
+    audio = rng.uniform(-1, 1, 16000 * seconds).astype(np.float32)
+    calls = []
+    inner, model.model = model.model, _recorded(model, calls)
+    try:
+        res = model.infer(audio, lang="en", max_length=48, normalize=False, trim_silence=False,
+                          condition_on_previous_text=conditioned, logits_filter=model.logits_filter)
+    finally:
+        model.model = inner
+    assert len(res["segments"]) >= 1 and len(calls) >= seconds // 30
     for seg in res["segments"]:
         assert seg["end"] >= seg["start"] >= 0.0
+    tok = osg.Tokens(lang_to_idx=model.vocabulary.lang_to_idx)
+    replay = iter(calls)
+    want, wcalls = osg.infer_segments(100 * seconds, lambda seek, prompt: next(replay)[1], tok, lang="en",
+                                      condition_on_previous_text=conditioned, max_length=48,
+                                      decode_text=model.decode_output)
+    assert [c[1] for c in wcalls] == [c[0] for c in calls]          # same prompts window by window
+    assert len(want) == len(res["segments"])
+    for g, w in zip(res["segments"], want):
+        assert g["start"] == w["start"] and g["end"] == w["end"] and g["text"] == w["text"]
+        assert np.array_equal(g["tokens"], w["tokens"])
     out = model.search("12", res, threshold=0.0)
     assert out["keyword"] == "12" and all(0.0 <= m["score"] <= 1.0 for m in out["matches"])
 
