@@ -123,6 +123,15 @@ int stt_engine_set_weight(stt_engine* engine, const char* name, const float* dat
 /* Converts to bf16, uploads, allocates every buffer on the current device. */
 int stt_engine_finalize(stt_engine* engine);
 
+/* Grows the capacity given to stt_engine_create (each argument: the new minimum; smaller values
+ * keep the current one) without touching the weights: waits for the device, frees and
+ * re-allocates the activation, cache and generation buffers only.  The encoded batch is lost
+ * (encode again before decoding).  The reference sizes its buffers per call from the prompt
+ * and max_length (architectures/generation_utils.py:96-169, 693-725); a caller whose prompt grows
+ * from window to window (models/stt/whisper.py:238-243) reserves once for the worst case. */
+int stt_engine_reserve(stt_engine* engine, int max_batch, int max_beams, int max_text_len,
+                       int max_prompt_len);
+
 /* d_mel: [batch][frames][n_mels] float32 on the device, frames <= 3000; shorter
  * windows are padded with 0.0 (BaseSTT.pad_or_trim, models/stt/base_stt.py:227-236).
  * Runs the encoder and the per-layer cross-attention K/V of the decoder
@@ -177,7 +186,8 @@ typedef struct {
  * out_scores: [batch][num_sentences] summed log-probabilities
  * (InferenceOutput of generation_utils.py:293-300, 466-481).  num_sentences is 1 for
  * greedy.  The work is ordered after what `stream` holds at the call, runs on a stream owned
- * by the engine (the per-token step is recorded once into a graph there and replayed) and has
+ * by the engine (the per-token step is recorded into a graph the first time a configuration is
+ * seen, kept on the engine and replayed) and has
  * finished, results in the host buffers, when the call returns.  Calls on one engine must not
  * overlap; two engines may run at the same time from two host threads. */
 int stt_generate(stt_engine* engine, const stt_generate_params* params, const int32_t* prompt,

@@ -8,6 +8,7 @@ torch is only used to own device memory and the stream.
 import json
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -107,6 +108,7 @@ class WhisperSTFT(MelSTFT):
         self._window = hann_window(self.win_length, periodic).astype(np.float32)
         self._device = torch.device(device) if device is not None else None
         self._plans = {}
+        self._plans_lock = threading.Lock()
         self._lib = _lib.load()
 
     def get_config(self):
@@ -115,21 +117,28 @@ class WhisperSTFT(MelSTFT):
         return config
 
     # -- device plumbing ---------------------------------------------------
-    def _plan(self, device):
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        if key not in self._plans:
-            import ctypes
-            handle = ctypes.c_void_p()
-            win = np.ascontiguousarray(self._window, dtype=np.float32)
-            basis = np.ascontiguousarray(self.mel_basis[0], dtype=np.float32)
-            with torch.cuda.device(key):
-                _lib.check(self._lib.stt_logmel_plan_create(
-                    int(self.n_mel_channels),
-                    win.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                    basis.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                    ctypes.byref(handle)))
-            self._plans[key] = handle
-        return self._plans[key]
+    def _plan(self, device, stream=None):
+        """The native plan for (device, stream).  A plan owns the counters its kernels synchronise
+        through, so calls on one plan must not overlap on the GPU: every stream gets its own
+        (threads that share a stream are ordered by that stream)."""
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        if stream is None:
+            stream = torch.cuda.current_stream(index).cuda_stream
+        key = (index, int(stream))
+        with self._plans_lock:
+            if key not in self._plans:
+                import ctypes
+                handle = ctypes.c_void_p()
+                win = np.ascontiguousarray(self._window, dtype=np.float32)
+                basis = np.ascontiguousarray(self.mel_basis[0], dtype=np.float32)
+                with torch.cuda.device(index):
+                    _lib.check(self._lib.stt_logmel_plan_create(
+                        int(self.n_mel_channels),
+                        win.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                        basis.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                        ctypes.byref(handle)))
+                self._plans[key] = handle
+            return self._plans[key]
 
     def __del__(self):
         try:

@@ -39,7 +39,12 @@ struct stt_engine {
   hipStream_t gen_stream = nullptr;    // generation runs here: a captured token step needs a real stream
   hipEvent_t gen_event = nullptr;
   std::map<std::string, std::vector<float>> host_w;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;           // weights: live as long as the engine
+  std::vector<void*> buf_allocs;       // activation / cache / state buffers: replaced by stt_engine_reserve
+  int* pinned = nullptr;               // page-locked host staging for prompts and results
+  size_t pinned_ints = 0;
+  // instantiated token-step graphs, keyed by everything the recorded launches bake in
+  std::map<std::string, hipGraphExec_t> step_graphs;
 
   // weights
   bf16_t *conv1_w = nullptr, *conv2_w = nullptr, *tok_emb = nullptr;
@@ -69,13 +74,30 @@ struct stt_engine {
 namespace {
 
 template <typename T>
-int dev_alloc(stt_engine* e, T** out, size_t count) {
+int dev_alloc_in(std::vector<void*>& owner, T** out, size_t count) {
   void* p = nullptr;
   const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
   STT_HIP_OR_FAIL(hipMalloc(&p, bytes), (void)0);
-  e->allocs.push_back(p);
+  owner.push_back(p);
   *out = (T*)p;
   return STT_OK;
+}
+template <typename T>
+int dev_alloc(stt_engine* e, T** out, size_t count) { return dev_alloc_in(e->allocs, out, count); }
+template <typename T>
+int buf_alloc(stt_engine* e, T** out, size_t count) { return dev_alloc_in(e->buf_allocs, out, count); }
+
+void drop_step_graphs(stt_engine* e) {
+  for (auto& kv : e->step_graphs) (void)hipGraphExecDestroy(kv.second);
+  e->step_graphs.clear();
+}
+void free_buffers(stt_engine* e) {
+  drop_step_graphs(e);
+  for (void* p : e->buf_allocs) (void)hipFree(p);
+  e->buf_allocs.clear();
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  e->pinned = nullptr;
+  e->pinned_ints = 0;
 }
 
 bf16_t host_f2bf(float f) {
@@ -201,6 +223,59 @@ void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const floa
   }
 }
 
+// Every buffer whose size depends on the capacity (max_batch, max_beams, max_len, max_prompt).
+int alloc_buffers(stt_engine* e) {
+  const stt_model_config& c = e->cfg;
+  const int d = c.n_audio_state, V = c.n_vocab;
+  int rc;
+  const size_t B = e->max_batch, T = 1500, H = c.n_audio_head;
+  const size_t R = B * T;
+  if ((rc = buf_alloc(e, &e->mel_pad, B * 3002 * c.n_mels + 4096)) ||
+      (rc = buf_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = buf_alloc(e, &e->ex, R * d)) ||
+      (rc = buf_alloc(e, &e->eh, R * d)) || (rc = buf_alloc(e, &e->eqkv, R * 3 * d)) ||
+      (rc = buf_alloc(e, &e->evt, B * H * 64 * 1536)) || (rc = buf_alloc(e, &e->eatt, R * d)) ||
+      (rc = buf_alloc(e, &e->ef, R * 4 * d)) || (rc = buf_alloc(e, &e->enc_out, R * d))) return rc;
+  STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
+  STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
+  e->cross_k.resize(c.n_text_layer); e->cross_v.resize(c.n_text_layer);
+  for (int l = 0; l < c.n_text_layer; ++l)
+    if ((rc = buf_alloc(e, &e->cross_k[l], B * H * T * 64)) ||
+        (rc = buf_alloc(e, &e->cross_v[l], B * H * T * 64))) return rc;
+
+  e->max_seq = e->max_batch * e->max_beams;
+  e->max_rows = e->max_seq * e->max_prompt;
+  const size_t S = e->max_seq, MR = e->max_rows, L = e->max_len;
+  const size_t slab_rows = MR < 256 ? MR : 256;
+  if ((rc = buf_alloc(e, &e->dx, MR * d)) || (rc = buf_alloc(e, &e->dh, MR * d)) ||
+      (rc = buf_alloc(e, &e->dqkv, MR * 3 * d)) || (rc = buf_alloc(e, &e->datt, MR * d)) ||
+      (rc = buf_alloc(e, &e->dq, MR * d)) || (rc = buf_alloc(e, &e->df, MR * 4 * d)) ||
+      (rc = buf_alloc(e, &e->slabs, (size_t)8 * slab_rows * d)) ||
+      (rc = buf_alloc(e, &e->tokens_in, MR)) || (rc = buf_alloc(e, &e->positions, MR))) return rc;
+  e->self_k.resize(c.n_text_layer); e->self_v.resize(c.n_text_layer);
+  for (int l = 0; l < c.n_text_layer; ++l)
+    if ((rc = buf_alloc(e, &e->self_k[l], S * H * L * 64)) ||
+        (rc = buf_alloc(e, &e->self_v[l], S * H * L * 64))) return rc;
+  GenState& g = e->gs;
+  if ((rc = buf_alloc(e, &g.logits, S * V)) || (rc = buf_alloc(e, &g.generated, S * L)) ||
+      (rc = buf_alloc(e, &g.lengths, S)) || (rc = buf_alloc(e, &g.scores, S)) ||
+      (rc = buf_alloc(e, &g.finished, S)) || (rc = buf_alloc(e, &g.next_token, S)) ||
+      (rc = buf_alloc(e, &g.base_len, S)) || (rc = buf_alloc(e, &g.slot_of, S * L)) ||
+      (rc = buf_alloc(e, &g.step, 64)) || (rc = buf_alloc(e, &g.cand_val, S)) ||
+      (rc = buf_alloc(e, &g.cand_idx, S)) || (rc = buf_alloc(e, &g.row_val, S * 16)) ||
+      (rc = buf_alloc(e, &g.row_idx, S * 16)) || (rc = buf_alloc(e, &g.generated_tmp, S * L)) ||
+      (rc = buf_alloc(e, &g.lengths_tmp, S)) || (rc = buf_alloc(e, &g.finished_tmp, S)) ||
+      (rc = buf_alloc(e, &g.slot_of_tmp, S * L)) || (rc = buf_alloc(e, &g.scores_tmp, S))) return rc;
+  g.all_finished = g.step + 16;
+  e->suppress_cap = 4096;
+  if ((rc = buf_alloc(e, &e->d_suppress, e->suppress_cap)) ||
+      (rc = buf_alloc(e, &e->d_suppress_first, e->suppress_cap))) return rc;
+  // page-locked staging: prompt tokens + positions, suppress lists, results, the "finished" flag
+  e->pinned_ints = 2 * MR + 2 * (size_t)e->suppress_cap + S * L + 2 * S + 64;
+  STT_HIP_OR_FAIL(hipHostMalloc((void**)&e->pinned, e->pinned_ints * sizeof(int), hipHostMallocDefault), (void)0);
+  return STT_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -238,6 +313,7 @@ int stt_engine_create(const stt_model_config* cfg, int max_batch, int max_beams,
 
 void stt_engine_destroy(stt_engine* e) {
   if (!e) return;
+  free_buffers(e);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
   if (e->gen_event) (void)hipEventDestroy(e->gen_event);
@@ -294,50 +370,27 @@ int stt_engine_finalize(stt_engine* e) {
     if ((rc = load_layer(e, "decoder.blocks." + std::to_string(l) + ".", d, true, e->dec[l]))) return rc;
   e->host_w.clear();
 
-  // ---- activation buffers
-  const size_t B = e->max_batch, T = 1500, H = c.n_audio_head;
-  const size_t R = B * T;
-  if ((rc = dev_alloc(e, &e->mel_pad, B * 3002 * c.n_mels + 4096)) ||
-      (rc = dev_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = dev_alloc(e, &e->ex, R * d)) ||
-      (rc = dev_alloc(e, &e->eh, R * d)) || (rc = dev_alloc(e, &e->eqkv, R * 3 * d)) ||
-      (rc = dev_alloc(e, &e->evt, B * H * 64 * 1536)) || (rc = dev_alloc(e, &e->eatt, R * d)) ||
-      (rc = dev_alloc(e, &e->ef, R * 4 * d)) || (rc = dev_alloc(e, &e->enc_out, R * d))) return rc;
-  STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
-  STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
-  e->cross_k.resize(c.n_text_layer); e->cross_v.resize(c.n_text_layer);
-  for (int l = 0; l < c.n_text_layer; ++l)
-    if ((rc = dev_alloc(e, &e->cross_k[l], B * H * T * 64)) ||
-        (rc = dev_alloc(e, &e->cross_v[l], B * H * T * 64))) return rc;
-
-  e->max_seq = e->max_batch * e->max_beams;
-  e->max_rows = e->max_seq * e->max_prompt;
-  const size_t S = e->max_seq, MR = e->max_rows, L = e->max_len;
-  const size_t slab_rows = MR < 256 ? MR : 256;
-  if ((rc = dev_alloc(e, &e->dx, MR * d)) || (rc = dev_alloc(e, &e->dh, MR * d)) ||
-      (rc = dev_alloc(e, &e->dqkv, MR * 3 * d)) || (rc = dev_alloc(e, &e->datt, MR * d)) ||
-      (rc = dev_alloc(e, &e->dq, MR * d)) || (rc = dev_alloc(e, &e->df, MR * 4 * d)) ||
-      (rc = dev_alloc(e, &e->slabs, (size_t)8 * slab_rows * d)) ||
-      (rc = dev_alloc(e, &e->tokens_in, MR)) || (rc = dev_alloc(e, &e->positions, MR))) return rc;
-  e->self_k.resize(c.n_text_layer); e->self_v.resize(c.n_text_layer);
-  for (int l = 0; l < c.n_text_layer; ++l)
-    if ((rc = dev_alloc(e, &e->self_k[l], S * H * L * 64)) ||
-        (rc = dev_alloc(e, &e->self_v[l], S * H * L * 64))) return rc;
-  GenState& g = e->gs;
-  if ((rc = dev_alloc(e, &g.logits, S * V)) || (rc = dev_alloc(e, &g.generated, S * L)) ||
-      (rc = dev_alloc(e, &g.lengths, S)) || (rc = dev_alloc(e, &g.scores, S)) ||
-      (rc = dev_alloc(e, &g.finished, S)) || (rc = dev_alloc(e, &g.next_token, S)) ||
-      (rc = dev_alloc(e, &g.base_len, S)) || (rc = dev_alloc(e, &g.slot_of, S * L)) ||
-      (rc = dev_alloc(e, &g.step, 64)) || (rc = dev_alloc(e, &g.cand_val, S)) ||
-      (rc = dev_alloc(e, &g.cand_idx, S)) || (rc = dev_alloc(e, &g.row_val, S * 16)) ||
-      (rc = dev_alloc(e, &g.row_idx, S * 16)) || (rc = dev_alloc(e, &g.generated_tmp, S * L)) ||
-      (rc = dev_alloc(e, &g.lengths_tmp, S)) || (rc = dev_alloc(e, &g.finished_tmp, S)) ||
-      (rc = dev_alloc(e, &g.slot_of_tmp, S * L)) || (rc = dev_alloc(e, &g.scores_tmp, S))) return rc;
-  g.all_finished = g.step + 16;
-  e->suppress_cap = 4096;
-  if ((rc = dev_alloc(e, &e->d_suppress, e->suppress_cap)) ||
-      (rc = dev_alloc(e, &e->d_suppress_first, e->suppress_cap))) return rc;
   e->finalized = true;
-  return STT_OK;
+  rc = alloc_buffers(e);
+  if (rc) e->finalized = false;
+  return rc;
+}
+
+int stt_engine_reserve(stt_engine* e, int max_batch, int max_beams, int max_text_len, int max_prompt_len) {
+  if (!e) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  const int nb = max_batch > e->max_batch ? max_batch : e->max_batch;
+  const int nm = max_beams > e->max_beams ? max_beams : e->max_beams;
+  const int nl = max_text_len > e->max_len ? max_text_len : e->max_len;
+  const int np = max_prompt_len > e->max_prompt ? max_prompt_len : e->max_prompt;
+  if (nb == e->max_batch && nm == e->max_beams && nl == e->max_len && np == e->max_prompt) return STT_OK;
+  if (nm > 16 || nl > e->cfg.n_text_ctx || nl > 512 || np >= nl || nb < 1)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "bad capacity (batch %d, beams %d, text %d, prompt %d)", nb, nm, nl, np);
+  STT_HIP_OR_FAIL(hipDeviceSynchronize(), (void)0);        // nothing may still read the old buffers
+  free_buffers(e);
+  e->max_batch = nb; e->max_beams = nm; e->max_len = nl; e->max_prompt = np;
+  e->enc_batch = 0;
+  return alloc_buffers(e);
 }
 
 // ------------------------------------------------------------------------------ encoder
@@ -535,22 +588,34 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   st = e->gen_stream;
   STT_HIP_OR_FAIL(hipStreamWaitEvent(st, e->gen_event, 0), (void)0);
 
-  // prompt repeated for every beam (generation_utils.py:448-451)
-  std::vector<int> tok((size_t)n_seq * prompt_len), pos((size_t)n_seq * prompt_len);
+  // prompt repeated for every beam (generation_utils.py:448-451); staged in page-locked memory so
+  // the copies are asynchronous and nothing has to be waited for before the first launch (the
+  // staging area is free again when the call returns: it ends with a stream synchronisation)
+  const size_t n_prompt = (size_t)n_seq * prompt_len;
+  int* h_tok = e->pinned;
+  int* h_pos = h_tok + e->max_rows;
+  int* h_sup = h_pos + e->max_rows;
+  int* h_sup1 = h_sup + e->suppress_cap;
+  int* h_fin = h_sup1 + e->suppress_cap;         // 64 ints
+  int* h_gen = h_fin + 64;                       // results: [max_seq * max_len], [max_seq], [max_seq]
+  int* h_len = h_gen + (size_t)e->max_seq * e->max_len;
+  float* h_sc = (float*)(h_len + e->max_seq);
   for (int i = 0; i < n_seq; ++i)
     for (int j = 0; j < prompt_len; ++j) {
-      tok[(size_t)i * prompt_len + j] = prompt[(size_t)(i / beams) * prompt_len + j];
-      pos[(size_t)i * prompt_len + j] = j;
+      h_tok[(size_t)i * prompt_len + j] = prompt[(size_t)(i / beams) * prompt_len + j];
+      h_pos[(size_t)i * prompt_len + j] = j;
     }
-  STT_HIP_OR_FAIL(hipMemcpyAsync(e->tokens_in, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, st), (void)0);
-  STT_HIP_OR_FAIL(hipMemcpyAsync(e->positions, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, st), (void)0);
-  if (p->n_suppress)
-    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress, p->suppress, p->n_suppress * 4, hipMemcpyHostToDevice, st), (void)0);
-  if (p->n_suppress_first)
-    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress_first, p->suppress_first, p->n_suppress_first * 4,
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->tokens_in, h_tok, n_prompt * 4, hipMemcpyHostToDevice, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->positions, h_pos, n_prompt * 4, hipMemcpyHostToDevice, st), (void)0);
+  if (p->n_suppress) {
+    memcpy(h_sup, p->suppress, (size_t)p->n_suppress * 4);
+    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress, h_sup, p->n_suppress * 4, hipMemcpyHostToDevice, st), (void)0);
+  }
+  if (p->n_suppress_first) {
+    memcpy(h_sup1, p->suppress_first, (size_t)p->n_suppress_first * 4);
+    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress_first, h_sup1, p->n_suppress_first * 4,
                                    hipMemcpyHostToDevice, st), (void)0);
-  // the pageable host buffers above must be consumed before they go out of scope or change
-  STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
+  }
   hipLaunchKernelGGL(init_state_kernel, dim3(n_seq), dim3(64), 0, st, gs, n_seq, prompt_len, e->max_len);
   hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, gs.generated, (long)n_seq * max_steps,
                      p->pad_token);
@@ -570,34 +635,48 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   if (rc) return rc;
   select(prompt_len);
 
-  // one token step = prepare inputs, decoder pass over one new token, selection
-  hipGraph_t graph = nullptr;
+  // One token step = prepare inputs, decoder pass over one new token, selection.  Recorded into a
+  // graph the first time a configuration is seen and kept on the engine: every quantity that
+  // changes from token to token lives in device memory, everything the launches bake in (sizes,
+  // filter and sampling parameters) is part of the key, and the buffers live until
+  // stt_engine_reserve / destroy, which drop the cache.
   hipGraphExec_t step_exec = nullptr;
   const char* no_graph = getenv("STT_MI355X_NO_GRAPH");
   if (max_steps > 1 && !(no_graph && no_graph[0] == '1')) {
-    STT_HIP_OR_FAIL(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), (void)0);
-    launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
-    rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
-    select(1);
-    const hipError_t cap = hipStreamEndCapture(st, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    STT_HIP_OR_FAIL(cap, (void)0);
-    STT_HIP_OR_FAIL(hipGraphInstantiate(&step_exec, graph, nullptr, nullptr, 0), (void)hipGraphDestroy(graph));
+    char key[320];
+    snprintf(key, sizeof key, "%d/%d/%d/%d/%d|%d/%d/%d|%a/%d/%a/%d/%a|%d/%d/%d/%d/%d|%d/%llu",
+             p->method, batch, beams, nsent, max_steps, p->eos_token, p->pad_token, p->early_stopping,
+             p->temperature, p->has_length_temperature, p->length_temperature, p->has_length_power,
+             p->length_power, p->n_suppress, p->n_suppress_first, p->timestamp_filter, p->timestamp_begin,
+             p->max_initial_timestamp, p->sample ? 1 : 0, (unsigned long long)(p->sample ? p->seed : 0));
+    auto hit = e->step_graphs.find(key);
+    if (hit != e->step_graphs.end()) {
+      step_exec = hit->second;
+    } else {
+      hipGraph_t graph = nullptr;
+      STT_HIP_OR_FAIL(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), (void)0);
+      launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
+      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+      select(1);
+      const hipError_t cap = hipStreamEndCapture(st, &graph);
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      STT_HIP_OR_FAIL(cap, (void)0);
+      const hipError_t inst = hipGraphInstantiate(&step_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      STT_HIP_OR_FAIL(inst, (void)0);
+      if (e->step_graphs.size() >= 16) drop_step_graphs(e);     // e.g. a fresh seed per call
+      e->step_graphs[key] = step_exec;
+    }
   }
-  auto drop_graph = [&]() {
-    if (step_exec) (void)hipGraphExecDestroy(step_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-  };
   const int check_every = p->check_every > 0 ? p->check_every : 8;
   for (int t = 1; t < max_steps; ++t) {
     if (p->early_stopping && (t % check_every) == 0) {
-      int fin = 0;
-      STT_HIP_OR_FAIL(hipMemcpyAsync(&fin, gs.all_finished, 4, hipMemcpyDeviceToHost, st), drop_graph());
-      STT_HIP_OR_FAIL(hipStreamSynchronize(st), drop_graph());
-      if (fin) break;
+      STT_HIP_OR_FAIL(hipMemcpyAsync(h_fin, gs.all_finished, 4, hipMemcpyDeviceToHost, st), (void)0);
+      STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
+      if (*h_fin) break;
     }
     if (step_exec) {
-      STT_HIP_OR_FAIL(hipGraphLaunch(step_exec, st), drop_graph());
+      STT_HIP_OR_FAIL(hipGraphLaunch(step_exec, st), (void)0);
     } else {
       launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
       rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
@@ -605,20 +684,16 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
       select(1);
     }
   }
-  STT_HIP_OR_FAIL(hipStreamSynchronize(st), drop_graph());
-  drop_graph();
   // results: [batch][nsent][max_steps]; lengths exclude the prompt (generation_utils.py:293-300)
-  std::vector<int> h_gen((size_t)n_seq * max_steps), h_len(n_seq);
-  std::vector<float> h_sc(n_seq);
-  STT_HIP_OR_FAIL(hipMemcpyAsync(h_gen.data(), gs.generated, h_gen.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
-  STT_HIP_OR_FAIL(hipMemcpyAsync(h_len.data(), gs.lengths, h_len.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
-  STT_HIP_OR_FAIL(hipMemcpyAsync(h_sc.data(), gs.scores, h_sc.size() * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_gen, gs.generated, (size_t)n_seq * max_steps * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_len, gs.lengths, (size_t)n_seq * 4, hipMemcpyDeviceToHost, st), (void)0);
+  STT_HIP_OR_FAIL(hipMemcpyAsync(h_sc, gs.scores, (size_t)n_seq * 4, hipMemcpyDeviceToHost, st), (void)0);
   STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   for (int b = 0; b < batch; ++b)
     for (int s = 0; s < nsent; ++s) {
       const int i = b * beams + s;
-      memcpy(out_tokens + ((size_t)b * nsent + s) * max_steps, h_gen.data() + (size_t)i * max_steps,
+      memcpy(out_tokens + ((size_t)b * nsent + s) * max_steps, h_gen + (size_t)i * max_steps,
              (size_t)max_steps * 4);
       out_lengths[b * nsent + s] = h_len[i] - prompt_len;
       out_scores[b * nsent + s] = h_sc[i];

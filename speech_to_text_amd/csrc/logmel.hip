@@ -507,8 +507,12 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
                       float* d_mel, float* d_piece_max, void* d_workspace, size_t workspace_bytes,
                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!plan || !d_pcm || !d_mel || !d_piece_max || !d_workspace)
-    return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!plan || !d_piece_max) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (frame_count == 0) {      // a piece without frames (more GPUs than tiles): only its maximum, -inf
+    hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
+    return STT_OK;
+  }
+  if (!d_pcm || !d_mel || !d_workspace) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   if (n_total < LM_NFFT)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "clip shorter than 400 samples (%lld): pad it first",
                     (long long)n_total);
@@ -517,10 +521,6 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
                     (long long)frame_begin, (long long)frame_count, (long long)(n_total / LM_HOP));
   if (((uintptr_t)d_pcm & 15) || ((uintptr_t)d_mel & 15))
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "d_pcm and d_mel must be 16-byte aligned");
-  if (frame_count == 0) {
-    hipLaunchKernelGGL(logmel_init, dim3(1), dim3(1), 0, stream, d_piece_max);
-    return STT_OK;
-  }
   // samples the frames touch inside the clip must be readable
   long need_lo = (long)frame_begin * LM_HOP - 200, need_hi = (long)(frame_begin + frame_count - 1) * LM_HOP + 200;
   if (need_lo < 0) need_lo = 0;
@@ -567,9 +567,9 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
 int stt_logmel_stage2(const stt_logmel_plan* plan, float* d_mel, int64_t frame_count,
                       const float* d_clip_max, const void* d_workspace, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (frame_count <= 0) return STT_OK;
   if (!plan || !d_mel || !d_clip_max || !d_workspace)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
-  if (frame_count <= 0) return STT_OK;
   const int n_seg = tiles_for(frame_count) * 4;
   const int grid = n_seg < 2048 ? n_seg : 2048;
   hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,

@@ -59,6 +59,37 @@ class TimestampFilter(object):
         self.eos_token_idx = int(eos_token_idx)
         self.max_initial_timestamp = int(max_initial_timestamp)
 
+    @classmethod
+    def from_callable(cls, fn):
+        """The reference enables its timestamp rules by handing `generation_utils.infer` a callable
+        (architectures/generation_utils.py:518-520): the free function `logits_filter(self, scores,
+        tokens, state)` of models/stt/whisper.py:414-416 bound to the model, as a
+        `functools.partial` or a bound method (or `timestamp_filter`, :354-412, with `to_remove`
+        given).  Such a callable is recognised by its name and translated from the model object it
+        carries (`remove_tokens`, `remove_tokens_with_space`, `timestamp_begin_idx`,
+        `eos_token_idx`); the rules themselves run on the device.  Anything else returns None:
+        arbitrary Python cannot run inside the device loop."""
+        import functools
+        owner, extra, func = None, {}, fn
+        if isinstance(fn, functools.partial):
+            func, extra = fn.func, dict(fn.keywords or {})
+            owner = fn.args[0] if fn.args else extra.pop('self', None)
+        elif getattr(fn, '__self__', None) is not None and hasattr(fn, '__func__'):
+            func, owner = fn.__func__, fn.__self__
+        name = getattr(func, '__name__', '')
+        if owner is None or name not in ('logits_filter', 'timestamp_filter'):
+            return None
+        try:
+            begin, eos = int(owner.timestamp_begin_idx), int(owner.eos_token_idx)
+            if name == 'timestamp_filter':
+                later = first = np.asarray(extra['to_remove'], np.int32).reshape(-1)
+            else:
+                later = np.asarray(owner.remove_tokens, np.int32).reshape(-1)
+                first = np.asarray(owner.remove_tokens_with_space, np.int32).reshape(-1)
+        except (AttributeError, KeyError):
+            return None
+        return cls(later, first, begin, eos, max_initial_timestamp=int(extra.get('max_initial_timestamp', 1)))
+
 
 class WhisperEngine(object):
     def __init__(self, dims, weights, max_batch=1, max_beams=1, max_text_len=256, max_prompt_len=4,
@@ -90,6 +121,16 @@ class WhisperEngine(object):
                 self._h = None
         except Exception:
             pass
+
+    def reserve(self, max_batch=0, max_beams=0, max_text_len=0, max_prompt_len=0):
+        """Grow the capacity (weights stay where they are); the encoded batch is dropped."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.stt_engine_reserve(self._h, int(max_batch), int(max_beams),
+                                                    int(max_text_len), int(max_prompt_len)))
+        self.max_batch, self.max_beams = max(self.max_batch, int(max_batch)), max(self.max_beams, int(max_beams))
+        self.max_text_len = max(self.max_text_len, int(max_text_len))
+        self.max_prompt_len = max(self.max_prompt_len, int(max_prompt_len))
+        self._batch = 0
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -162,6 +203,14 @@ class WhisperEngine(object):
         if p.sample:
             p.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
         keep = []
+        if callable(logits_filter) and not isinstance(logits_filter, TimestampFilter):
+            translated = TimestampFilter.from_callable(logits_filter)
+            if translated is None:
+                raise ValueError("logits_filter: only the reference's Whisper `logits_filter` / "
+                                 "`timestamp_filter` bound to a model (functools.partial or bound "
+                                 "method) can be translated to the device loop; pass that, a "
+                                 "TimestampFilter or a list of token ids")
+            logits_filter = translated
         if isinstance(logits_filter, TimestampFilter):
             a, bb = logits_filter.remove_tokens, logits_filter.remove_tokens_with_space
             keep += [a, bb]
@@ -172,9 +221,6 @@ class WhisperEngine(object):
             p.max_initial_timestamp = logits_filter.max_initial_timestamp
             p.eos_token = int(eos_token)
         elif logits_filter is not None:
-            if callable(logits_filter):
-                raise ValueError("a Python callable cannot run inside the device loop: pass a "
-                                 "TimestampFilter or a list of token ids")
             a = np.ascontiguousarray(np.asarray(logits_filter, dtype=np.int32).reshape(-1))
             keep.append(a)
             p.suppress, p.n_suppress = a.ctypes.data_as(C.POINTER(C.c_int32)), a.size
@@ -207,6 +253,8 @@ def _declare(lib):
     lib.stt_engine_set_weight.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), i64]
     lib.stt_engine_finalize.restype = i32
     lib.stt_engine_finalize.argtypes = [vp]
+    lib.stt_engine_reserve.restype = i32
+    lib.stt_engine_reserve.argtypes = [vp, i32, i32, i32, i32]
     lib.stt_encode.restype = i32
     lib.stt_encode.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.stt_decoder_forward.restype = i32
@@ -218,4 +266,4 @@ def _declare(lib):
 
 
 ENGINE_SYMBOLS = ("stt_engine_create", "stt_engine_destroy", "stt_engine_set_weight",
-                  "stt_engine_finalize", "stt_encode", "stt_decoder_forward", "stt_generate")
+                  "stt_engine_finalize", "stt_engine_reserve", "stt_encode", "stt_decoder_forward", "stt_generate")

@@ -59,7 +59,6 @@ class _Engine(object):
     def __init__(self, dims, weights, gelu_tanh=True):
         self.dims, self.weights, self.gelu_tanh = dims, weights, gelu_tanh
         self._built = {}      # replica -> WhisperEngine
-        self._cap = {}        # replica -> (batch, beams, text_len, prompt_len)
         self._locks = collections.defaultdict(threading.RLock)
         self._guard = threading.Lock()
 
@@ -70,18 +69,26 @@ class _Engine(object):
             return self._locks[replica]
 
     def get(self, batch, beams, text_len, prompt_len, replica=0):
-        """Engine `replica` (0 unless a caller pipelines batches over several engines), rebuilt
-        when a call needs more capacity than it was built for."""
-        cap = self._cap.get(replica)
-        if cap is None or batch > cap[0] or beams > cap[1] or text_len > cap[2] or prompt_len > cap[3]:
-            new = (max(batch, cap[0] if cap else 1), max(beams, cap[1] if cap else 1),
-                   max(text_len, cap[2] if cap else 2), max(prompt_len, cap[3] if cap else 1))
-            self._built.pop(replica, None)
-            self._built[replica] = WhisperEngine(self.dims, self.weights, max_batch=new[0],
-                                                 max_beams=new[1], max_text_len=new[2],
-                                                 max_prompt_len=new[3], gelu_tanh=self.gelu_tanh)
-            self._cap[replica] = new
-        return self._built[replica]
+        """Engine `replica` (0 unless a caller pipelines batches over several engines).
+
+        Built once for the text side's worst case - every position of the decoder context and a
+        prompt of half of it plus the task tokens, which is what the reference's long-form loop
+        grows to window by window (models/stt/whisper.py:238-243) - so that neither a longer
+        prompt nor `encoder()` followed by `decoder()` ever changes it.  Only a larger batch or
+        more beams than any call before grows it, through stt_engine_reserve: buffers are
+        re-allocated, the weights stay on the device."""
+        ctx = min(int(self.dims['n_text_ctx']), 512)
+        text_len = min(ctx, max(text_len, ctx))
+        prompt_len = max(prompt_len, min(ctx - 1, ctx // 2 + 3))
+        eng = self._built.get(replica)
+        if eng is None:
+            eng = WhisperEngine(self.dims, self.weights, max_batch=batch, max_beams=beams,
+                                max_text_len=text_len, max_prompt_len=prompt_len, gelu_tanh=self.gelu_tanh)
+            self._built[replica] = eng
+        elif (batch > eng.max_batch or beams > eng.max_beams or text_len > eng.max_text_len
+              or prompt_len > eng.max_prompt_len):
+            eng.reserve(batch, beams, text_len, prompt_len)
+        return eng
 
 
 class MI355XRuntime(Runtime):
@@ -162,6 +169,7 @@ class MI355XRuntime(Runtime):
         with self.engine.lock(replica):
             eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s,
                                   replica=replica)
+            self.engine._state_owner = None        # the encoded batch of an earlier encoder() call is gone
             eng.encode(mel)
             if on_encoded is not None:
                 ev = torch.cuda.Event()
@@ -178,21 +186,46 @@ class MI355XRuntime(Runtime):
 
     # -- callables used by detect_language --------------------------------
     def encoder(self, mel, training=False, **_):
+        """Encoder output [B, 1500, d] (float32 CUDA tensor).  The engine also keeps the encoded
+        batch (and its cross-attention K/V) for a following `decoder` call."""
         if not isinstance(mel, torch.Tensor):
             mel = torch.from_numpy(np.ascontiguousarray(np.asarray(mel, dtype=np.float32)))
         if mel.dim() == 2:
             mel = mel[None]
         with self.engine.lock():
             eng = self.engine.get(max(mel.shape[0], self._max_batch), 1, 8, 4)
-            return eng.encode(mel, return_output=True)
+            out = eng.encode(mel, return_output=True)
+            self._mark_state_owner()
+            self._encoded = (out.data_ptr(), tuple(out.shape), out._version, mel)
+            return out
 
     def decoder(self, tokens, encoder_output=None, training=False, **_):
-        """Logits [B, S, V] of a teacher-forced pass over the windows last given to ``encoder``
-        (``encoder_output`` is accepted for signature parity; the engine keeps its own copy)."""
+        """Logits [B, S, V] of a teacher-forced pass (whisper.py:181-183).  `encoder_output` must be
+        what the last `encoder` call on this runtime returned, untouched: the engine decodes
+        against the K/V it derived from it.  If another call has used the engine in between (the
+        lock is not held across the two calls) the windows are encoded again first; a tensor the
+        engine never produced is refused."""
         tokens = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens, dtype=np.int32)
         if tokens.ndim == 1:
             tokens = tokens[None]
         with self.engine.lock():
             eng = self.engine.get(max(tokens.shape[0], self._max_batch), 1, max(8, tokens.shape[1] + 1),
                                   max(4, tokens.shape[1]))
+            if encoder_output is not None:
+                known = getattr(self, '_encoded', None)
+                same = (known is not None and isinstance(encoder_output, torch.Tensor)
+                        and encoder_output.data_ptr() == known[0] and tuple(encoder_output.shape) == known[1]
+                        and encoder_output._version == known[2])
+                if not same:
+                    raise ValueError('encoder_output is not the (unmodified) tensor the last encoder() call '
+                                     'returned: the engine decodes against its own copy of the encoder state')
+                if self._state_owner() is not self:
+                    eng.encode(known[3])
+            self._mark_state_owner()
             return eng.decoder_logits(tokens)
+
+    def _state_owner(self):
+        return getattr(self.engine, '_state_owner', None)
+
+    def _mark_state_owner(self):
+        self.engine._state_owner = self

@@ -98,6 +98,10 @@ class Whisper(object):
         self.pad_mel_value = 0.
         self.vocabulary = vocabulary or WhisperVocabulary()
         if path is None:
+            import warnings
+            warnings.warn("Whisper(pretrained = {!r}) without `path`: no checkpoint can be downloaded here, "
+                          "using SEEDED RANDOM weights - transcripts will be meaningless. Pass path = <weights> "
+                          "(or path = 'random:<size>' to silence this)".format(pretrained), stacklevel=2)
             path = 'random:{}'.format(pretrained)
         self.model = build_runtime(runtime, path, max_batch=max_batch,
                                    **{k: v for k, v in kwargs.items() if k in ('gelu', 'reload')})

@@ -397,3 +397,32 @@ def test_beam_search_finished_beams(small):
         et, el, es = engine.generate(one, max_new_tokens=16, early_stopping=True, check_every=check_every, **kw)
         assert np.array_equal(et[:, :, :stop], ft) and (et[:, :, stop:] == 0).all()
         assert np.array_equal(el, fl) and np.allclose(es, fs, atol=1e-5)
+
+
+def test_reserve_keeps_weights_and_cached_graphs_replay(small):
+    """stt_engine_reserve grows the buffers without touching the weights: same tokens before and
+    after; a second call with the same configuration replays the cached token-step graph, a
+    different configuration records its own."""
+    from speech_to_text_amd.engine import WhisperEngine
+    dims, _, oracle, mel = small
+    w = _bf16_round(om.random_weights(dims, seed=0, style="peaked"))
+    engine = WhisperEngine(_dims_dict(dims), w, max_batch=1, max_beams=1, max_text_len=16, max_prompt_len=4)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    kw = dict(max_new_tokens=10, eos_token=999, pad_token=999, early_stopping=False)
+    engine.encode(mel[:1])
+    first, _, s_first = engine.generate(prompt[:1], **kw)
+    again, _, _ = engine.generate(prompt[:1], **kw)                  # cache hit
+    assert np.array_equal(first, again)
+    engine.reserve(max_batch=3, max_beams=4, max_text_len=40, max_prompt_len=12)
+    with pytest.raises(Exception):
+        engine.generate(prompt[:1], **kw)                            # the encoded batch is gone
+    engine.encode(mel)
+    wide, _, s_wide = engine.generate(prompt, **kw)
+    assert np.array_equal(wide[0], first[0]) and abs(s_wide[0] - s_first[0]) < 1e-4
+    beams, _, _ = engine.generate(prompt, method="beam", num_beams=4, num_sentences=1, **kw)
+    wide2, _, _ = engine.generate(prompt, **kw)                      # greedy graph still valid after the beam one
+    assert np.array_equal(wide, wide2) and beams.shape == (3, 1, 10)
+    long_prompt = np.tile(np.array([[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]], dtype=np.int32), [3, 1])
+    out, _, sc = engine.generate(long_prompt, **kw)
+    with torch.no_grad():
+        P.check_greedy_steps(oracle, oracle.encoder(mel), long_prompt, out, 999, 999, scores=sc)

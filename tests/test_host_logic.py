@@ -119,3 +119,30 @@ def test_logits_masks():
         want = logits.copy(); want[1, 3] = want[4, 0] = -np.inf
         assert np.array_equal(unwrap(mask_tokens(wrap(logits), [[1, 3], [4, 0]])), want)
     assert np.array_equal(logits, keep)
+
+
+def test_reference_callable_filter_is_translated():
+    """The reference passes its timestamp rules as a callable bound to the model
+    (models/stt/whisper.py:414-416): recognised by name, translated from the model's attributes;
+    unknown callables are refused."""
+    import functools
+    import types
+    from speech_to_text_amd.engine import TimestampFilter
+
+    def logits_filter(self, scores, tokens, state, **_):        # stands for the reference's free function
+        raise AssertionError("never called on the host")
+
+    def timestamp_filter(self, scores, tokens, to_remove, state, max_initial_timestamp=1, **_):
+        raise AssertionError("never called on the host")
+
+    model = types.SimpleNamespace(remove_tokens=np.array([5, 6]), remove_tokens_with_space=np.array([220, 50257, 5, 6]),
+                                  timestamp_begin_idx=50364, eos_token_idx=50257)
+    for fn in (functools.partial(logits_filter, model), types.MethodType(logits_filter, model),
+               functools.partial(logits_filter, self=model)):
+        f = TimestampFilter.from_callable(fn)
+        assert f.remove_tokens.tolist() == [5, 6] and f.remove_tokens_with_space.tolist() == [220, 50257, 5, 6]
+        assert (f.timestamp_begin_idx, f.eos_token_idx, f.max_initial_timestamp) == (50364, 50257, 1)
+    f = TimestampFilter.from_callable(functools.partial(timestamp_filter, model, to_remove=[7], max_initial_timestamp=0))
+    assert f.remove_tokens.tolist() == [7] and f.max_initial_timestamp == 0
+    assert TimestampFilter.from_callable(lambda scores, **kw: scores) is None
+    assert TimestampFilter.from_callable(functools.partial(logits_filter, object())) is None
