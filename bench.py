@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X Whisper hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload logmel]
+    python bench.py --gpus N --steps K --warmup W [--workload whisper|logmel]
 
-Workload `logmel` (BASELINE.json configs[1]): log-mel frontend over 1 h of synthetic
-16 kHz audio (uniform(-1,1) float32, already resident in HBM), 80 mel bins, fp32.
-One step = one full pass (both kernels) over the clip.  With N > 1 every rank owns
-its own 1 h clip (independent clips, no data-path collective): weak scaling.
+Default workload `whisper` (BASELINE.json's metric "audio-sec transcribed/sec, whisper-large-v3
+greedy", configs[3]): 10 h of synthetic 16 kHz audio = 1200 windows of 30 s, dealt round-robin to
+the ranks (`dist.window_shard`), every rank holding the PCM of its windows in HBM.  One step =
+the whole 10 h once: per batch of windows log-mel -> encoder -> cross K/V -> 128 greedy tokens
+(early stopping off: random weights never emit EOS reliably), then the per-window token lists
+gathered on every rank - inside the timed region.  Total work is fixed as N grows: strong scaling.
+The same line carries the log-mel workload (configs[1]: 1 h of audio, 80 mel bins, fp32, one
+full pass per step, per-rank clips) under "logmel" with its own roofline and CPU baseline.
 
-Prints ONE JSON line on rank 0.
+`--workload logmel` runs only the frontend line (weak scaling: every rank owns its own clip).
+
+With `--gpus N > 1` and no RANK in the environment the script starts N ranks itself (one
+process per GPU, RCCL) before anything touches a GPU; under torch.distributed.run it uses the
+ranks it is given.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,30 +32,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16
+PROMPT = [50258, 50259, 50359]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="logmel")
-    ap.add_argument("--hours", type=float, default=1.0, help="audio hours per rank and step")
+    ap.add_argument("--steps", type=int, default=None, help="default: 2 (whisper) / 50 (logmel)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 1 (whisper) / 5 (logmel)")
+    ap.add_argument("--workload", default="whisper", choices=("whisper", "logmel"))
+    ap.add_argument("--hours", type=float, default=1.0, help="logmel: audio hours per rank and step")
     ap.add_argument("--n-mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", default="large-v3", help="whisper leg / workload: model size")
-    ap.add_argument("--batch", type=int, default=256, help="whisper: 30 s windows per step and GPU")
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--windows", type=int, default=1200, help="whisper: 30 s windows in the job (10 h)")
+    ap.add_argument("--batch", type=int, default=256, help="whisper: windows per engine call at most")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--replicas", type=int, default=2,
-                    help="whisper: 2 adds the pipelined two-engine measurement, 1 skips it")
+    ap.add_argument("--logmel-steps", type=int, default=50, help="steps of the log-mel leg of the whisper line (0 = skip)")
+    ap.add_argument("--pipelined", type=int, default=1, help="whisper: also measure two engines per GPU, one phase apart")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
-    ap.add_argument("--whisper-steps", type=int, default=2,
-                    help="steps of the extra whisper leg reported beside the log-mel workload (0 = skip)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 2 if a.workload == "whisper" else 50
+    if a.warmup is None:
+        a.warmup = 1 if a.workload == "whisper" else 5
+    return a
 
 
-def init_dist(n, backend="nccl"):
+# ------------------------------------------------------------------------------ launching
+def spawn_ranks(args):
+    """`--gpus N` given to a plain `python bench.py`: start N ranks (no GPU call has been made in
+    this process), relay their output, return the worst exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    return max(p.wait() for p in procs)
+
+
+def init_dist(backend):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,7 +91,13 @@ def init_dist(n, backend="nccl"):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()
     return rank, world, local
+
+
+def _coll_device():
+    import torch.distributed as dist
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
 
 def barrier(world):
@@ -73,7 +110,7 @@ def barrier(world):
 def max_over_ranks(x, world):
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
@@ -84,20 +121,18 @@ def all_ranks_ok(ok, world):
     whose leg raised (out of memory, ...) does not leave the others waiting in a barrier."""
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_coll_device())
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
     return bool(ok)
 
 
-# HBM bytes per logmel_main launch from the rocprofv3 PMC passes of this build (FETCH_SIZE x 2,
-# the gfx950 correction, + WRITE_SIZE; profiles/r1/logmel_1h_pmc_hbm.csv).  Counters cannot be
-# read from inside this process, so only the profiled configuration has a value.
-MEASURED_HBM_BYTES = {(57_600_000, 80): 368884285}
+def host_threads():
+    return min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
 
 
-def bench_logmel(args, rank, world):
+# ------------------------------------------------------------------------------ log-mel
+def bench_logmel(args, rank, world, steps, warmup):
     from speech_to_text_amd import _lib
     from speech_to_text_amd.audio.stft import WhisperSTFT
 
@@ -119,11 +154,11 @@ def bench_logmel(args, rank, world):
         _lib.check(lib.stt_logmel_run(plan, pcm.data_ptr(), n, mel.data_ptr(), ws.data_ptr(),
                                       ws_bytes, stream))
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0            # this rank's K steps; the closing barrier is not timed
@@ -131,12 +166,12 @@ def bench_logmel(args, rank, world):
     dt = max_over_ranks(dt, world)
 
     alg_bytes = n * 4 + frames * args.n_mels * 4          # each sample read once, each mel written once
-    value = world * args.steps * alg_bytes / dt / 1e9      # GB/s, whole job
+    value = world * steps * alg_bytes / dt / 1e9           # GB/s, whole job
 
     # dominant kernel (logmel_main), timed with events on the launching stream
     piece_max = ws[:4].view(torch.float32)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+           for _ in range(steps)]
     torch.cuda.synchronize()
     for a, b in evs:
         a.record()
@@ -148,14 +183,15 @@ def bench_logmel(args, rank, world):
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "logmel_main<%d>" % args.n_mels, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": MEASURED_HBM_BYTES.get((n, args.n_mels)), "kernel_ms": round(k_ms, 4),
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "traffic": None, "traffic_note": "HBM bytes cannot be read from inside the process: see "
+                "the rocprofv3 --pmc passes under profiles/ (FETCH_SIZE / WRITE_SIZE) for this kernel",
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import frontend as oracle
-        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        sample_s = 3600
+        threads = host_threads()
+        sample_s = min(3600, n // 16000)
         host = pcm[: sample_s * 16000].cpu().numpy()
         oracle.whisper_log_mel_torch(host[:1_600_000], args.n_mels, threads=threads)
         best = 1e30
@@ -175,26 +211,23 @@ def bench_logmel(args, rank, world):
         cpu["max_abs_diff_vs_gpu"] = float(np.abs(got - ref[: got.shape[0]]).max()) \
             if sample_s * 16000 == n else None
 
-    line = {
+    return {
         "metric": "log-mel GB/s (algorithmic bytes: PCM read once + mel written once)",
-        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "log-mel frontend, %.3g h of 16 kHz audio per GPU, %d mel bins, fp32 "
                    "(BASELINE.json configs[1])" % (args.hours, args.n_mels),
                    "audio_seconds_per_step": world * n / 16000.0},
-        "audio_sec_per_sec": round(world * args.steps * (n / 16000.0) / dt, 1),
+        "audio_sec_per_sec": round(world * steps * (n / 16000.0) / dt, 1),
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    return line
 
 
-MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16
-
-
+# ------------------------------------------------------------------------------ whisper
 def whisper_flops(dims, batch, new_tokens, prompt_len):
-    """Algorithmic FLOPs (2 per multiply-add) of one step: encoder + cross-K/V + decode."""
+    """Algorithmic FLOPs (2 per multiply-add): encoder, cross-K/V, decode of `batch` windows."""
     d, L, T, M = dims["n_audio_state"], dims["n_audio_layer"], 1500, dims["n_mels"]
     stem = 2 * 3000 * 3 * M * d + 2 * T * 3 * d * d
     layer = 2 * T * (4 * d * d + 8 * d * d) + 4 * T * T * d
@@ -204,200 +237,239 @@ def whisper_flops(dims, batch, new_tokens, prompt_len):
     return batch * enc, batch * cross, batch * tok * (new_tokens + prompt_len - 1)
 
 
-def decode_roofline(dims, batch, ms_per_token):
-    """HBM roofline of one token step: the decoder's bf16 weights are read once per step, the
-    cross-attention K/V of every window once per step (the dominant term), self K/V ignored."""
+def token_step_bytes(dims, batch):
+    """Algorithmic HBM bytes of one greedy token step: the decoder's bf16 weights once, the
+    cross-attention K/V of every window once (the dominant term); self K/V ignored."""
     d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
-    weights = (L * 14 * d * d + V * d) * 2
-    cross_kv = batch * L * 2 * 1500 * d * 2
-    achieved = (weights + cross_kv) / (ms_per_token * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "scope": "whole token step (all kernels), algorithmic bytes: decoder weights + cross K/V",
-            "algorithmic_bytes_per_step": weights + cross_kv}
+    return (L * 14 * d * d + V * d) * 2 + batch * L * 2 * 1500 * d * 2
 
 
-def bench_whisper(args, rank, world, steps, warmup, with_cpu):
-    """Whisper greedy over `batch` synthetic 30 s windows per step: PCM (resident in HBM) ->
-    log-mel -> encoder -> cross K/V -> `new_tokens` greedy tokens, early stopping off (random
-    weights never emit EOS reliably).  BASELINE.json configs[3] per GPU (configs[2] with
-    --model base)."""
+def bench_whisper(args, rank, world):
+    """BASELINE configs[3].  Returns the headline line (rank 0 keeps it)."""
+    import torch.distributed as dist
     from speech_to_text_amd.audio.stft import WhisperSTFT
+    from speech_to_text_amd.dist import gather_window_results, window_shard
     from speech_to_text_amd.engine import WhisperEngine, whisper_dims
     from speech_to_text_amd.weights import random_whisper_weights
 
     dims = whisper_dims(args.model)
-    prompt_row = [50258, 50259, 50359]
+    steps, warmup = args.steps, args.warmup
     err = None
     try:
+        mine = window_shard(args.windows, rank, world)
+        per_call = min(args.batch, max(1, len(mine)))
+        batches = [mine[i: i + per_call] for i in range(0, len(mine), per_call)]
         weights = random_whisper_weights(dims, 0)
-        eng = WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
-                            max_text_len=args.new_tokens + len(prompt_row) + 1, max_prompt_len=4)
+        eng = WhisperEngine(dims, weights, max_batch=per_call, max_beams=1,
+                            max_text_len=args.new_tokens + len(PROMPT) + 1, max_prompt_len=4)
         fn = WhisperSTFT(n_mel_channels=dims["n_mels"])
         dev = torch.device("cuda", torch.cuda.current_device())
-        rng = np.random.default_rng(100 + rank)
-        pcm = torch.from_numpy(rng.uniform(-1, 1, args.batch * 480000).astype(np.float32)).to(dev)
-        prompt = np.array([prompt_row] * args.batch, dtype=np.int32)
+        # this rank's windows, resident in HBM: uniform(-1, 1) noise seeded by the window index
+        pcm = torch.empty((len(mine), 480000), dtype=torch.float32, device=dev)
+        for i, w in enumerate(mine):
+            pcm[i] = torch.from_numpy(np.random.default_rng(1000 + w).uniform(-1, 1, 480000).astype(np.float32))
+
+        def run_batch(lo, hi, engine=eng, mel_fn=fn):
+            n = hi - lo
+            mel = mel_fn(pcm[lo:hi].reshape(-1))[0].view(n, 3000, dims["n_mels"])     # 30 s = 3000 frames exactly
+            engine.encode(mel)
+            prompt = np.array([PROMPT] * n, dtype=np.int32)
+            return engine.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
+                                   early_stopping=False)
 
         def step():
-            mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])       # 30 s = 3000 frames exactly
-            eng.encode(mel)
-            return eng.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
-                                early_stopping=False)
+            local, lo = {}, 0
+            for ws_ in batches:
+                toks, lens, _ = run_batch(lo, lo + len(ws_))
+                for j, w in enumerate(ws_):
+                    local[w] = toks[j, : lens[j]]
+                lo += len(ws_)
+            return gather_window_results(local)          # KB-scale all_gather_object, part of the step
 
         for _ in range(warmup):
             step()
     except Exception as e:                  # noqa: BLE001
         err = e
     if not all_ranks_ok(err is None, world):
-        raise err if err is not None else RuntimeError("another rank failed to set up the whisper leg")
+        raise err if err is not None else RuntimeError("another rank failed to set up the whisper workload")
     barrier(world)
     t0 = time.perf_counter()
     try:
         for _ in range(steps):
-            toks, lens, _ = step()
+            merged = step()
         torch.cuda.synchronize()
     except Exception as e:                  # noqa: BLE001
         err = e
     dt = time.perf_counter() - t0
     barrier(world)
     if not all_ranks_ok(err is None, world):
-        raise err if err is not None else RuntimeError("another rank failed in the whisper leg")
+        raise err if err is not None else RuntimeError("another rank failed in the whisper workload")
     dt = max_over_ranks(dt, world)
+    assert sorted(merged) == list(range(args.windows)), "gather lost windows"
+    audio_s = steps * args.windows * 30.0
 
-    # encoder alone (MFMA-bound part), event-timed on the launching stream
-    mel = fn(pcm)[0].view(args.batch, 3000, dims["n_mels"])
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- phases of one full batch on this rank, event-timed on the launching stream
+    n_b = len(batches[0])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     torch.cuda.synchronize()
-    a.record(); eng.encode(mel); b.record()
+    ev[0].record()
+    mel = fn(pcm[:n_b].reshape(-1))[0].view(n_b, 3000, dims["n_mels"])
+    ev[1].record()
+    eng.encode(mel)
+    ev[2].record()
     torch.cuda.synchronize()
-    enc_ms = a.elapsed_time(b)
-    f_enc, f_cross, f_dec = whisper_flops(dims, args.batch, args.new_tokens, len(prompt_row))
-    audio_s = world * steps * args.batch * 30.0
-    out = {
+    mel_ms, enc_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    t1 = time.perf_counter()
+    eng.generate(np.array([PROMPT] * n_b, dtype=np.int32), max_new_tokens=args.new_tokens, eos_token=50257,
+                 pad_token=50257, early_stopping=False)
+    gen_ms = (time.perf_counter() - t1) * 1e3
+    tok_ms = gen_ms / args.new_tokens
+    f_enc, f_cross, _ = whisper_flops(dims, n_b, args.new_tokens, len(PROMPT))
+
+    # ---- dominant kernel: the decoder's cross-attention, one launch per layer and token.  Timed
+    # live with events around single launches on this stream (stt_engine_probe_kernel issues the
+    # launch of a token step; inside stt_generate it sits in a replayed graph).
+    probes = []
+    for it in range(3 * dims["n_text_layer"]):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.probe_kernel(0, it % dims["n_text_layer"])
+        b.record()
+        probes.append((a, b))
+    torch.cuda.synchronize()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in probes[dims["n_text_layer"]:]]))
+    k_bytes = n_b * 2 * 1500 * dims["n_text_state"] * 2           # K and V of every window, bf16, one layer
+    k_gbs = k_bytes / (k_ms * 1e-3) / 1e9
+    launches = dims["n_text_layer"] * args.new_tokens * len(batches)
+    roofline = {"bound": "hbm", "kernel": "attn_decoder_cross_kernel", "achieved": round(k_gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "traffic_note": "not measurable in-process; rocprofv3 --pmc pass of this command under profiles/",
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": k_bytes,
+                "windows_per_launch": n_b, "launches_per_step_and_rank": launches,
+                "share_of_step": round(launches * k_ms * 1e-3 / (dt / steps), 3)}
+    step_bytes = token_step_bytes(dims, n_b)
+    line = {
         "metric": "audio-sec transcribed/sec, whisper-%s greedy" % args.model,
-        "value": round(audio_s / dt, 1), "unit": "audio-s/s", "n_gpus": world, "steps": steps,
-        "ms_per_step": round(dt / steps * 1e3, 2),
-        "config": {"workload": "whisper-%s greedy, %d x 30 s synthetic windows per GPU and step, "
-                   "%d new tokens, bf16" % (args.model, args.batch, args.new_tokens)},
-        "dtype": "bf16", "data": "synthetic",
-        "encoder_ms": round(enc_ms, 2),
-        "roofline_encoder": {"bound": "mfma", "achieved": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12, 1),
-                             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                             "scope": "whole encoder pass + cross K/V (all kernels), algorithmic FLOPs"},
-        "decode_ms_per_token": round((dt / steps * 1e3 - enc_ms) / args.new_tokens, 3),
-        "roofline_decode": decode_roofline(dims, args.batch, (dt / steps * 1e3 - enc_ms) / args.new_tokens),
-        "tokens_generated_per_window": int(lens[0]),
+        "value": round(audio_s / dt, 1), "unit": "audio-s/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "whisper-%s greedy, %d x 30 s synthetic windows (%.3g h) dealt round-robin to "
+                   "%d rank(s), <= %d windows per engine call, %d new tokens per window, token lists gathered "
+                   "on every rank (BASELINE.json configs[3])" % (args.model, args.windows, args.windows / 120.0,
+                                                                 world, per_call, args.new_tokens),
+                   "audio_seconds_per_step": args.windows * 30.0, "windows_per_call": per_call,
+                   "calls_per_step_and_rank": len(batches),
+                   "note": "log-mel per engine call over that call's windows (clamp maximum per call)"},
+        "audio_hours_per_hour": round(audio_s / dt, 1),
+        "roofline": roofline,
+        "phases_rank0": {
+            "windows": n_b, "logmel_ms": round(mel_ms, 3), "encoder_ms": round(enc_ms, 2),
+            "generate_ms": round(gen_ms, 2), "ms_per_token": round(tok_ms, 3),
+            "roofline_encoder": {"bound": "mfma", "achieved": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12, 1),
+                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round((f_enc + f_cross) / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                 "scope": "whole encoder pass + cross K/V (all kernels), algorithmic FLOPs"},
+            "roofline_token_step": {"bound": "hbm", "achieved": round(step_bytes / (tok_ms * 1e-3) / 1e9, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(step_bytes / (tok_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "scope": "whole token step (all kernels, host loop included): decoder "
+                                    "weights + cross K/V", "algorithmic_bytes_per_step": step_bytes}},
     }
-    if args.batch > 32:
-        # the batch size BASELINE.json's configs[3] names (32 windows per GPU), on the same engine;
-        # this rank's own time (no collective), scaled by the number of ranks
-        try:
-            p32 = prompt[:32]
 
-            def step32():
-                mel32 = fn(pcm[: 32 * 480000])[0].view(32, 3000, dims["n_mels"])
-                eng.encode(mel32)
-                eng.generate(p32, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
-                             early_stopping=False)
+    # ---- the batch size BASELINE.json's configs[3] names (32 windows per GPU), same engine
+    try:
+        run_batch(0, min(32, n_b))
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        for _ in range(2):
+            run_batch(0, min(32, n_b))
+        torch.cuda.synchronize()
+        t32 = (time.perf_counter() - t32) / 2
+        line["batch32"] = {"value": round(min(32, n_b) * 30.0 / t32, 1), "unit": "audio-s/s per GPU",
+                           "ms_per_call": round(t32 * 1e3, 2), "note": "32 windows per engine call, this rank alone"}
+    except Exception as e:                  # noqa: BLE001
+        line["batch32"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
-            step32()
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            for _ in range(2):
-                step32()
-            torch.cuda.synchronize()
-            t32 = (time.perf_counter() - t32) / 2
-            out["batch32"] = {"value": round(world * 32 * 30.0 / t32, 1), "unit": "audio-s/s",
-                              "ms_per_step": round(t32 * 1e3, 2),
-                              "note": "32 windows per GPU and step (BASELINE.json configs[3] batch size), rank 0's time"}
-        except Exception as e:              # noqa: BLE001
-            out["batch32"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if with_cpu and rank == 0 and world == 1:
-        from oracle import model as om
-        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        torch.set_num_threads(threads)
-        odims = om.Dims(**{k: dims[k] for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head",
-                                                "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
-                                                "n_text_head", "n_text_layer")})
-        oracle = om.Whisper(odims, weights)
-        mel1 = mel[:1].cpu()
-        n_tok = 8
-        with torch.no_grad():
-            t = time.perf_counter()
-            ref = om.greedy(oracle, mel1, torch.tensor([prompt_row]), max_new_tokens=n_tok, eos=50257,
-                            pad=50257, early_stopping=False)
-            cpu_s = time.perf_counter() - t
-        # extrapolate the decode part to new_tokens tokens: report the measured sample as is
-        out["cpu_baseline"] = {"value": round(30.0 / cpu_s, 3), "unit": "audio-s/s", "cores": threads,
-                               "kind": "port", "seconds": round(cpu_s, 2),
-                               "sample": "1 window, encoder + %d greedy tokens (not %d), torch-CPU fp32 "
-                               "restatement (oracle/model.py) on the same weights" % (n_tok, args.new_tokens),
-                               "first_tokens_match_gpu": bool((ref["tokens"][0].numpy() == toks[0][:n_tok]).all())}
-    if args.replicas >= 2:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = whisper_cpu_baseline(args, dims, weights, mel[:1].cpu(), merged[mine[0]])
+    if args.pipelined and len(batches) >= 2:
         try:                                # every rank raises together (all_ranks_ok)
-            out["pipelined"] = bench_whisper_pipelined(args, dims, weights, eng, fn, pcm, prompt, world, steps)
+            line["pipelined"] = bench_pipelined(args, dims, weights, eng, fn, run_batch, batches, world)
         except Exception as e:              # noqa: BLE001
-            out["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del eng
-    return out
+    return line
 
 
-def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, steps):
-    """The same step on two engines built from the same weights, each on its own host thread and
-    stream, the second one phase late: while one decodes a batch (HBM bound) the other runs the
-    log-mel and the encoder of its next batch (matrix-core bound).  Every replica does `steps`
-    steps; the time includes the unoverlapped first and last phases."""
+def whisper_cpu_baseline(args, dims, weights, mel1, gpu_tokens):
+    """oracle/model.py (torch-CPU float32 restatement of the reference) on one window: encoder and
+    a bounded number of greedy tokens, timed separately and put together for the workload's
+    128 tokens per window."""
+    from oracle import model as om
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    odims = om.Dims(**{k: dims[k] for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head",
+                                            "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
+                                            "n_text_head", "n_text_layer")})
+    oracle = om.Whisper(odims, weights)
+    n_tok = 24
+    with torch.no_grad():
+        t = time.perf_counter()
+        enc = oracle.encoder(mel1)
+        t_enc = time.perf_counter() - t
+        t = time.perf_counter()
+        ref = om.greedy(oracle, enc=enc, prompt=torch.tensor([PROMPT]), max_new_tokens=n_tok, eos=50257,
+                        pad=50257, early_stopping=False)
+        t_dec = time.perf_counter() - t
+    per_window = t_enc + t_dec * args.new_tokens / n_tok
+    return {"value": round(30.0 / per_window, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "seconds": round(t_enc + t_dec, 2),
+            "sample": "1 window: encoder %.1f s + cross K/V and %d greedy tokens %.1f s measured (torch-CPU fp32, "
+            "oracle/model.py, same weights); value = 30 s / (encoder + tokens scaled to %d)"
+            % (t_enc, n_tok, t_dec, args.new_tokens),
+            "first_tokens_match_gpu": bool(np.array_equal(ref["tokens"][0].numpy(), np.asarray(gpu_tokens)[:n_tok]))}
+
+
+def bench_pipelined(args, dims, weights, eng0, fn0, run_batch, batches, world):
+    """This rank's batches alternated over two engines built from the same weights, each on its own
+    host thread and stream, the second one phase late: while one decodes a batch (HBM bound) the
+    other runs the log-mel and the encoder of its next batch (matrix-core bound).  One pass over
+    the rank's windows; the time includes the unoverlapped first and last phases."""
     import threading
     from speech_to_text_amd.audio.stft import WhisperSTFT
     from speech_to_text_amd.engine import WhisperEngine
-    dev = pcm.device
-    first = threading.Event()
-    box, errors = {}, []
+    dev = torch.device("cuda", torch.cuda.current_device())
+    errors = []
     engs, fns = [eng0], [fn0]
     try:
-        engs.append(WhisperEngine(dims, weights, max_batch=args.batch, max_beams=1,
-                                  max_text_len=args.new_tokens + 8, max_prompt_len=4))
-        fns.append(WhisperSTFT(n_mel_channels=dims["n_mels"]))    # a log-mel plan serves one stream
+        engs.append(WhisperEngine(dims, weights, max_batch=len(batches[0]), max_beams=1,
+                                  max_text_len=args.new_tokens + len(PROMPT) + 1, max_prompt_len=4))
+        fns.append(fn0)                      # plans are per stream
+        run_batch(0, len(batches[0]), engs[1], fns[1])       # warm the second engine
+        torch.cuda.synchronize()
     except Exception as e:                   # noqa: BLE001
         errors.append(e)
+    if not all_ranks_ok(not errors, world):
+        raise errors[0] if errors else RuntimeError("another rank failed to set up the pipelined leg")
+    starts = np.cumsum([0] + [len(b) for b in batches])
+    first = threading.Event()
 
-    def one(r, signal=False):
-        mel = fns[r](pcm)[0].view(args.batch, 3000, dims["n_mels"])
-        engs[r].encode(mel)
-        if signal:
-            box["event"] = torch.cuda.Event()
-            box["event"].record()
-            first.set()
-        engs[r].generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
-                         early_stopping=False)
-
-    def worker(r, n):
+    def worker(r):
         try:
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
                 if r == 1:
                     first.wait()
-                    if "event" in box:
-                        box["event"].synchronize()
-                for i in range(n):
-                    one(r, signal=(r == 0 and i == 0))
+                for i in range(r, len(batches), 2):
+                    run_batch(int(starts[i]), int(starts[i + 1]), engs[r], fns[r])
+                    first.set()
         except BaseException as e:
             errors.append(e)
         finally:
             first.set()
 
-    try:
-        if not errors:
-            one(1)                           # warm the second engine (the first one is warm)
-            torch.cuda.synchronize()
-    except Exception as e:                   # noqa: BLE001
-        errors.append(e)
-    if not all_ranks_ok(not errors, world):
-        raise errors[0] if errors else RuntimeError("another rank failed to set up the pipelined leg")
     barrier(world)
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(r, steps)) for r in range(2)]
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
     for t in threads:
         t.start()
     for t in threads:
@@ -408,26 +480,26 @@ def bench_whisper_pipelined(args, dims, weights, eng0, fn0, pcm, prompt, world, 
     if not all_ranks_ok(not errors, world):
         raise errors[0] if errors else RuntimeError("another rank failed in the pipelined leg")
     dt = max_over_ranks(dt, world)
-    return {"value": round(world * 2 * steps * args.batch * 30.0 / dt, 1), "unit": "audio-s/s",
-            "replicas": 2, "steps_per_replica": steps, "seconds": round(dt, 3),
-            "note": "two engines per GPU, encode of one batch overlapped with decode of the other"}
+    return {"value": round(args.windows * 30.0 / dt, 1), "unit": "audio-s/s", "replicas": 2, "seconds": round(dt, 3),
+            "note": "one pass over the job, two engines per GPU, encode of one batch overlapped with decode "
+            "of another (no token gather)"}
 
 
 def main():
     args = parse()
-    rank, world, local = init_dist(args.gpus, args.dist_backend)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rank, world, local = init_dist(args.dist_backend)
     if args.workload == "logmel":
-        line = bench_logmel(args, rank, world)
-        if args.whisper_steps > 0:
+        line = bench_logmel(args, rank, world, args.steps, args.warmup)
+    else:
+        line = bench_whisper(args, rank, world)
+        if args.logmel_steps > 0:
             # the extra leg must never cost the headline line: report its failure instead
             try:
-                line["whisper"] = bench_whisper(args, rank, world, args.whisper_steps, 1,
-                                                not args.no_cpu_baseline)
+                line["logmel"] = bench_logmel(args, rank, world, args.logmel_steps, 5)
             except Exception as e:          # noqa: BLE001  (every rank raises together: all_ranks_ok)
-                line["whisper"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    else:
-        w = bench_whisper(args, rank, world, args.steps, args.warmup, not args.no_cpu_baseline)
-        line = dict(w, warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None)
+                line["logmel"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

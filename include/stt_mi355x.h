@@ -147,6 +147,13 @@ int stt_encode(stt_engine* engine, const float* d_mel, int batch, int frames, fl
 int stt_decoder_forward(stt_engine* engine, const int32_t* tokens, int batch, int n_tokens,
                         float* d_logits, void* stream);
 
+/* Measurement aid, no counterpart in the reference: enqueues on `stream` one launch of a hot
+ * kernel exactly as a greedy token step over the last encoded batch issues it, so that a
+ * benchmark can bracket it with events on its own stream (inside stt_generate the kernel runs
+ * in a replayed graph on an engine-owned stream).  Results are discarded. */
+#define STT_PROBE_CROSS_ATTENTION 0   /* attn_decoder_cross_kernel of decoder layer `layer` */
+int stt_engine_probe_kernel(stt_engine* engine, int kernel, int layer, void* stream);
+
 #define STT_METHOD_GREEDY 0
 #define STT_METHOD_BEAM 1
 

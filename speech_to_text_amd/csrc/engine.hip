@@ -548,6 +548,31 @@ int stt_decoder_forward(stt_engine* e, const int32_t* tokens, int batch, int n_t
   return STT_OK;
 }
 
+int stt_engine_probe_kernel(stt_engine* e, int kernel, int layer, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (e->enc_batch < 1) return stt_fail(STT_ERR_INVALID_ARGUMENT, "nothing encoded");
+  if (layer < 0 || layer >= e->cfg.n_text_layer) return stt_fail(STT_ERR_INVALID_ARGUMENT, "no such layer");
+  const int d = e->cfg.n_text_state, H = e->cfg.n_text_head;
+  if (kernel == STT_PROBE_CROSS_ATTENTION) {
+    // exactly the launch of a greedy token step: one new token per window, the query read as
+    // split-K partial sums (whatever the last step left in them: timing only)
+    const int rows = e->enc_batch;
+    const LayerW& L = e->dec[layer];
+    CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[layer], e->cross_v[layer], e->datt,
+                     rows, 1, 1, H, 1500};
+    if (rows <= 256) {
+      ca.q_slabs = e->slabs; ca.n_q_slabs = pick_split_k(rows, d, d, e->n_cu);
+      ca.q_slab_stride = (long)rows * d; ca.q_bias = L.bq_c;
+    }
+    launch_attn_decoder_cross(ca, st);
+  } else {
+    return stt_fail(STT_ERR_UNSUPPORTED, "unknown probe %d", kernel);
+  }
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
 int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* prompt, int batch,
                  int prompt_len, int32_t* out_tokens, int32_t* out_lengths, float* out_scores,
                  void* stream_) {

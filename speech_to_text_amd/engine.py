@@ -132,6 +132,11 @@ class WhisperEngine(object):
         self.max_prompt_len = max(self.max_prompt_len, int(max_prompt_len))
         self._batch = 0
 
+    def probe_kernel(self, kernel=0, layer=0):
+        """One launch of a hot kernel on the current stream (stt_engine_probe_kernel): for timing."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.stt_engine_probe_kernel(self._h, int(kernel), int(layer), self._stream()))
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -255,6 +260,8 @@ def _declare(lib):
     lib.stt_engine_finalize.argtypes = [vp]
     lib.stt_engine_reserve.restype = i32
     lib.stt_engine_reserve.argtypes = [vp, i32, i32, i32, i32]
+    lib.stt_engine_probe_kernel.restype = i32
+    lib.stt_engine_probe_kernel.argtypes = [vp, i32, i32, vp]
     lib.stt_encode.restype = i32
     lib.stt_encode.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.stt_decoder_forward.restype = i32
@@ -266,4 +273,4 @@ def _declare(lib):
 
 
 ENGINE_SYMBOLS = ("stt_engine_create", "stt_engine_destroy", "stt_engine_set_weight",
-                  "stt_engine_finalize", "stt_engine_reserve", "stt_encode", "stt_decoder_forward", "stt_generate")
+                  "stt_engine_finalize", "stt_engine_reserve", "stt_engine_probe_kernel", "stt_encode", "stt_decoder_forward", "stt_generate")
