@@ -325,14 +325,17 @@ __device__ __forceinline__ float sum8(float v) {
   return v;
 }
 
-template <int CQ>
-__global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttnArgs a) {
+// NWV waves per block: 4 when there are enough (window, head) blocks to cover the chip, 16 for a
+// few windows (one clip: 20 blocks), where a block of 4 waves cannot keep enough loads in flight
+// to pull its 384 KB at more than ~20 GB/s.
+template <int CQ, int NWV>
+__global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const CrossAttnArgs a) {
   constexpr int U = CQ == 1 ? 6 : CQ == 2 ? 4 : 2;     // loads in flight per wave
   __shared__ float sc[CQ][CROSS_MAX_T];
   __shared__ float qs[CQ][64];
-  __shared__ float red[4][CQ][64];
-  __shared__ float wmax[4][CQ];
-  __shared__ float wsum[4][CQ];
+  __shared__ float red[NWV][CQ][64];
+  __shared__ float wmax[NWV][CQ];
+  __shared__ float wsum[NWV][CQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int piece = lane & 7, kg = lane >> 3;
   const int h = blockIdx.x, win = blockIdx.y;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
 
   for (int qc = 0; qc < nq_total; qc += CQ) {
     const int nq = nq_total - qc < CQ ? nq_total - qc : CQ;
-    for (int e = tid; e < CQ * 64; e += 256) {
+    for (int e = tid; e < CQ * 64; e += 64 * NWV) {
       const int qi = e >> 6, d = e & 63;
       float qv = 0.f;
       if (qi < nq) {
@@ -370,16 +373,16 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
     float mx[CQ];
 #pragma unroll
     for (int qi = 0; qi < CQ; ++qi) mx[qi] = -__builtin_inff();
-    for (int k0 = wave * 8 + kg; k0 < T; k0 += 32 * U) {
+    for (int k0 = wave * 8 + kg; k0 < T; k0 += 8 * NWV * U) {
       cross_u4 u[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int key = k0 + 32 * j < T ? k0 + 32 * j : T - 1;
+        const int key = k0 + 8 * NWV * j < T ? k0 + 8 * NWV * j : T - 1;
         u[j] = __builtin_nontemporal_load((const cross_u4*)(kb + (long)key * 64));
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int key = k0 + 32 * j;
+        const int key = k0 + 8 * NWV * j;
         float kv[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(u[j][e] << 16); kv[2 * e + 1] = __uint_as_float(u[j][e] & 0xFFFF0000u); }
@@ -404,8 +407,12 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
     }
     __syncthreads();
 #pragma unroll
-    for (int qi = 0; qi < CQ; ++qi)
-      mx[qi] = fmaxf(fmaxf(wmax[0][qi], wmax[1][qi]), fmaxf(wmax[2][qi], wmax[3][qi]));
+    for (int qi = 0; qi < CQ; ++qi) {
+      float m = wmax[0][qi];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) m = fmaxf(m, wmax[w][qi]);
+      mx[qi] = m;
+    }
 
     // P V with the weights exponentiated on the fly
     float acc[CQ][8], sum[CQ];
@@ -415,16 +422,16 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
     }
-    for (int k0 = wave * 8 + kg; k0 < T; k0 += 32 * U) {
+    for (int k0 = wave * 8 + kg; k0 < T; k0 += 8 * NWV * U) {
       cross_u4 u[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int key = k0 + 32 * j < T ? k0 + 32 * j : T - 1;
+        const int key = k0 + 8 * NWV * j < T ? k0 + 8 * NWV * j : T - 1;
         u[j] = __builtin_nontemporal_load((const cross_u4*)(vb + (long)key * 64));
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const int key = k0 + 32 * j;
+        const int key = k0 + 8 * NWV * j;
         float vv[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vv[2 * e] = __uint_as_float(u[j][e] << 16); vv[2 * e + 1] = __uint_as_float(u[j][e] & 0xFFFF0000u); }
@@ -450,10 +457,18 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
       if (lane == 0) wsum[wave][qi] = sm;
     }
     __syncthreads();
-    for (int e = tid; e < nq * 64; e += 256) {
+    for (int e = tid; e < nq * 64; e += 64 * NWV) {
       const int qi = e >> 6, d = e & 63;
-      const float inv = 1.0f / (wsum[0][qi] + wsum[1][qi] + wsum[2][qi] + wsum[3][qi]);
-      const float v = (red[0][qi][d] + red[1][qi][d] + red[2][qi][d] + red[3][qi][d]) * inv;
+      float den = 0.f, num = 0.f;
+      if (NWV == 4) {            // the summation order of the four-wave kernel as it always was
+        den = wsum[0][qi] + wsum[1][qi] + wsum[2][qi] + wsum[3][qi];
+        num = red[0][qi][d] + red[1][qi][d] + red[2][qi][d] + red[3][qi][d];
+      } else {
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { den += wsum[w][qi]; num += red[w][qi][d]; }
+      }
+      const float inv = 1.0f / den;
+      const float v = num * inv;
       a.out[(row0 + qc + qi) * d_model + h * 64 + d] = f2bf(v);
     }
     __syncthreads();
@@ -463,10 +478,15 @@ __global__ __launch_bounds__(256) void attn_decoder_cross_kernel(const CrossAttn
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream) {
   const int nq = a.seq_per_win * a.s_new;
   const dim3 grid(a.heads, a.n_win);
-  if (nq == 1) hipLaunchKernelGGL(attn_decoder_cross_kernel<1>, grid, dim3(256), 0, stream, a);
-  else if (nq == 2) hipLaunchKernelGGL(attn_decoder_cross_kernel<2>, grid, dim3(256), 0, stream, a);
-  else if (nq <= 4) hipLaunchKernelGGL(attn_decoder_cross_kernel<4>, grid, dim3(256), 0, stream, a);
+  if (a.heads * a.n_win <= 96 && nq <= 2) {          // a few windows: sixteen waves per block
+    if (nq == 1) hipLaunchKernelGGL((attn_decoder_cross_kernel<1, 16>), grid, dim3(1024), 0, stream, a);
+    else hipLaunchKernelGGL((attn_decoder_cross_kernel<2, 16>), grid, dim3(1024), 0, stream, a);
+    return;
+  }
+  if (nq == 1) hipLaunchKernelGGL((attn_decoder_cross_kernel<1, 4>), grid, dim3(256), 0, stream, a);
+  else if (nq == 2) hipLaunchKernelGGL((attn_decoder_cross_kernel<2, 4>), grid, dim3(256), 0, stream, a);
+  else if (nq <= 4) hipLaunchKernelGGL((attn_decoder_cross_kernel<4, 4>), grid, dim3(256), 0, stream, a);
   else if (nq <= 6 || (nq > 8 && nq % 8 != 0 && nq % 6 == 0))
-    hipLaunchKernelGGL(attn_decoder_cross_kernel<6>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(attn_decoder_cross_kernel<8>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_decoder_cross_kernel<6, 4>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((attn_decoder_cross_kernel<8, 4>), grid, dim3(256), 0, stream, a);
 }
