@@ -192,10 +192,11 @@ typedef struct {
  * out_lengths: [batch][num_sentences] generated tokens without the EOS,
  * out_scores: [batch][num_sentences] summed log-probabilities
  * (InferenceOutput of generation_utils.py:293-300, 466-481).  num_sentences is 1 for
- * greedy.  The work is ordered after what `stream` holds at the call, runs on a stream owned
- * by the engine (the per-token step is recorded into a graph the first time a configuration is
- * seen, kept on the engine and replayed) and has
- * finished, results in the host buffers, when the call returns.  Calls on one engine must not
+ * greedy.  The work is ordered after what `stream` holds at the call and runs on it (the
+ * per-token step is recorded into a graph the first time a configuration is seen, kept on the
+ * engine and replayed); the legacy default stream (NULL) cannot be captured, so then the work
+ * runs on a stream the engine owns.  It has finished, results in the host buffers, when the
+ * call returns.  Calls on one engine must not
  * overlap; two engines may run at the same time from two host threads. */
 int stt_generate(stt_engine* engine, const stt_generate_params* params, const int32_t* prompt,
                  int batch, int prompt_len, int32_t* out_tokens, int32_t* out_lengths,

@@ -597,21 +597,25 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   const int n_seq = batch * beams, V = e->cfg.n_vocab, max_steps = p->max_steps;
   GenState& gs = e->gs;
 
-  // Generation runs on the engine's own stream, ordered after the caller's: the token step is
-  // recorded once into a graph (every per-token quantity lives in device memory, so the
-  // recorded launches are the same for every token) and replayed, and the caller's stream may
-  // be the legacy default stream, which cannot be captured.
-  hipStream_t user_st = st;
-  if (!e->gen_stream) {
-    // default priority on purpose: with a high-priority stream here, two engines driven from two
-    // host threads (one encoding on its caller's stream while the other generates) stopped making
-    // progress on ROCm 7.2, and the gain without the hang was within noise
-    STT_HIP_OR_FAIL(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking), (void)0);
-    STT_HIP_OR_FAIL(hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming), (void)0);
+  // The token step is recorded into a graph (every per-token quantity lives in device memory, so
+  // the recorded launches are the same for every token) and replayed.  A stream the caller
+  // created can be captured directly, so generation runs there.  Only the legacy default stream
+  // cannot: then the work moves to a stream the engine owns, ordered after the caller's by an
+  // event.  Worker threads that bring their own streams (two engines, one encoding while the
+  // other decodes) therefore add no stream and no cross-stream wait of their own: two workers
+  // use two streams, which stays within the four hardware queues a process gets here.  (An
+  // earlier version always switched streams, at high priority: with two workers that made five
+  // software streams in two priority classes for four hardware queues, the waits between them
+  // hung in the queue scheduler, and it was dropped.)
+  if (st == nullptr) {
+    if (!e->gen_stream) {
+      STT_HIP_OR_FAIL(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking), (void)0);
+      STT_HIP_OR_FAIL(hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming), (void)0);
+    }
+    STT_HIP_OR_FAIL(hipEventRecord(e->gen_event, nullptr), (void)0);
+    st = e->gen_stream;
+    STT_HIP_OR_FAIL(hipStreamWaitEvent(st, e->gen_event, 0), (void)0);
   }
-  STT_HIP_OR_FAIL(hipEventRecord(e->gen_event, user_st), (void)0);
-  st = e->gen_stream;
-  STT_HIP_OR_FAIL(hipStreamWaitEvent(st, e->gen_event, 0), (void)0);
 
   // prompt repeated for every beam (generation_utils.py:448-451); staged in page-locked memory so
   // the copies are asynchronous and nothing has to be waited for before the first launch (the

@@ -33,9 +33,20 @@ InferenceOutput = collections.namedtuple(
 
 def _load_state_dict(path):
     if os.path.isdir(path):
-        for name in sorted(os.listdir(path)):
-            if name.endswith(('.safetensors', '.pt', '.pth', '.npz')):
-                return _load_state_dict(os.path.join(path, name))
+        # a plain weight directory, or a model directory written by the reference
+        # (pretrained_models/<name>/{config.json, saving/...}, models/interfaces/base_model.py:126-136)
+        for folder in (path, os.path.join(path, 'saving')):
+            if not os.path.isdir(folder):
+                continue
+            for name in sorted(os.listdir(folder)):
+                if name.endswith(('.safetensors', '.pt', '.pth', '.npz')):
+                    return _load_state_dict(os.path.join(folder, name))
+        keras_ckpt = [n for f in (path, os.path.join(path, 'saving')) if os.path.isdir(f)
+                      for n in os.listdir(f) if n.endswith('.weights.h5')]
+        if keras_ckpt:
+            raise FileNotFoundError(
+                '{} holds a Keras checkpoint ({}) but no converted weights: run `python tools/convert_keras_weights.py '
+                '{}` once where h5py is installed (it writes saving/weights.npz)'.format(path, keras_ckpt[-1], path))
         raise FileNotFoundError('no weight file (*.safetensors, *.pt, *.npz) in {}'.format(path))
     if path.endswith('.safetensors'):
         from safetensors.torch import load_file

@@ -5,6 +5,8 @@ plus ``search`` (README "Search and partial alignment").
 
 Host code (Python) like the reference's wrapper; everything numeric runs in the runtime.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -19,6 +21,31 @@ LANGUAGES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk 
              "no th ur hr bg lt la mi ml cy sk te fa lv bn sr az sl kn et mk br eu is hy ne mn bs kk "
              "sq sw gl mr pa si km sn yo so af oc ka be tg sd gu am yi lo uz fo ht ps tk nn mt sa lb "
              "my bo tl mg as tt haw ln ha ba jw su").split()
+
+
+class _ReferenceTokenizer(object):
+    """Decoding and single-token lookups from the reference's own tokenizer file: token strings in
+    byte-level BPE spelling (`vocab`) and the byte <-> character table (`byte_encoder`).  Enough
+    for what the wrapper needs (ids -> text, ' ' and symbol lookups); encoding free text is the
+    caller's business, as the prompt ids are."""
+
+    def __init__(self, config):
+        self.vocab = list(config['vocab'])
+        self.index = {t: i for i, t in enumerate(self.vocab)}
+        table = config.get('byte_encoder') or {}
+        self.to_char = {int(k): v for k, v in table.items()}
+        self.to_byte = {v: k for k, v in self.to_char.items()}
+
+    def decode(self, ids):
+        text = ''.join(self.vocab[i] for i in ids if 0 <= i < len(self.vocab))
+        if not self.to_byte:
+            return text
+        return bytearray(self.to_byte.get(c, ord('?')) for c in text).decode('utf-8', errors='replace')
+
+    def encode(self, text, add_special_tokens=False):
+        spelled = ''.join(self.to_char.get(b, '') for b in text.encode('utf-8')) if self.to_char else text
+        hit = self.index.get(spelled)
+        return type('Encoding', (), {'ids': [hit] if hit is not None else []})()
 
 
 class WhisperVocabulary(object):
@@ -41,9 +68,29 @@ class WhisperVocabulary(object):
         self.nospeech_token_idx = 50362
         self.notimestamps_idx = 50363
         self.timestamp_begin_idx = vocab_size
+        names = getattr(tokenizer, 'index', None)
+        if names and '<|endoftext|>' in names and '<|startoftranscript|>' in names:
+            # ids from the file instead of the whisper-base constants (a large-v3 tokenizer has one
+            # more language, which shifts every id after it)
+            self.eos_token_idx, self.sos_token_idx = names['<|endoftext|>'], names['<|startoftranscript|>']
+            self.lang_to_idx = {l: names['<|%s|>' % l] for l in LANGUAGES + ['yue'] if '<|%s|>' % l in names}
+            self.idx_to_lang = {i: l for l, i in self.lang_to_idx.items()}
+            for attr, token in (('translate_token_idx', '<|translate|>'), ('transcribe_token_idx', '<|transcribe|>'),
+                                ('start_of_lm_idx', '<|startoflm|>'), ('start_of_prev_token_idx', '<|startofprev|>'),
+                                ('nospeech_token_idx', '<|nospeech|>'), ('notimestamps_idx', '<|notimestamps|>')):
+                if token in names:
+                    setattr(self, attr, names[token])
+            self.vocab_size = self.timestamp_begin_idx = names.get('<|0.00|>', len(names))
 
     @classmethod
     def from_file(cls, tokenizer_json):
+        """A Hugging Face `tokenizer.json`, or the `saving/tokenizer.json` the reference writes
+        (`Tokenizer.save`, utils/text/tokenizer.py:671-706: a `vocab` list and a `byte_encoder`)."""
+        import json
+        with open(tokenizer_json, encoding='utf-8') as f:
+            head = json.load(f)
+        if isinstance(head.get('vocab'), list):
+            return cls(_ReferenceTokenizer(head))
         from tokenizers import Tokenizer
         return cls(Tokenizer.from_file(tokenizer_json))
 
@@ -96,6 +143,8 @@ class Whisper(object):
         self.max_input_length = 3000
         self.max_output_length = 256
         self.pad_mel_value = 0.
+        if vocabulary is None and isinstance(path, str) and os.path.isfile(os.path.join(path, 'saving', 'tokenizer.json')):
+            vocabulary = WhisperVocabulary.from_file(os.path.join(path, 'saving', 'tokenizer.json'))
         self.vocabulary = vocabulary or WhisperVocabulary()
         if path is None:
             import warnings
@@ -106,7 +155,15 @@ class Whisper(object):
         self.model = build_runtime(runtime, path, max_batch=max_batch,
                                    **{k: v for k, v in kwargs.items() if k in ('gelu', 'reload')})
         n_mels = self.model.dims['n_mels']
-        self.mel_fn = WhisperSTFT(n_mel_channels=n_mels)
+        mel_file = os.path.join(path, 'saving', 'mel_fn.json') if isinstance(path, str) else ''
+        if os.path.isfile(mel_file):                  # written by the reference's MelSTFT.save (stft.py:164-182)
+            from ..audio.stft import MelSTFT
+            self.mel_fn = MelSTFT.create(mel_file)
+            if self.mel_fn.n_mel_channels != n_mels:
+                raise ValueError('{} has {} mel channels, the weights expect {}'.format(
+                    mel_file, self.mel_fn.n_mel_channels, n_mels))
+        else:
+            self.mel_fn = WhisperSTFT(n_mel_channels=n_mels)
         self.trim_kwargs = dict(trim_silence=True, **WHISPER_TRIM_KWARGS)
         self.model.set_tokens(sos_token=self.sos_token_idx, eos_token=self.eos_token_idx,
                               pad_token=self.eos_token_idx)

@@ -215,3 +215,28 @@ def test_split_frontend_equals_whole_clip():
     clip_max = torch.stack(maxima).max(dim=0).values
     out = torch.cat([fn.finish_piece(m, clip_max, st) for m, st in pieces]).cpu().numpy()
     assert out.shape == whole.shape and np.array_equal(out, whole)
+
+
+def test_reference_model_directory(golden_dir):
+    """`Whisper(path = <directory the reference wrote>)`: converted Keras weights, the reference's
+    tokenizer file and mel configuration; one decoder step against the oracle on the same weights."""
+    from oracle import model as om
+    from speech_to_text_amd.stt import Whisper
+    from speech_to_text_amd.runtimes.mi355x_runtime import _load_state_dict
+    from tests._parity import rel_l2
+    path = os.path.join(golden_dir, "keras_model_dir")
+    stt = Whisper(path=path)
+    assert stt.eos_token_idx == 400 and stt.timestamp_begin_idx == 418 and stt.model.dims["n_vocab"] == 512
+    assert len(stt.remove_tokens) > 5 and stt.mel_fn.n_mel_channels == 80
+    sd = {k: v.to(torch.bfloat16).float() for k, v in _load_state_dict(path).items()}
+    d = stt.model.dims
+    oracle = om.Whisper(om.Dims(**{k: d[k] for k in om.Dims.__dataclass_fields__}), sd)
+    mel = stt.get_input(os.path.join(golden_dir, "audio_test.wav"), pad_or_trim=True)[None]
+    prompt = np.array([stt.get_inference_tokens(lang="en")], dtype=np.int32)
+    got = stt.model.decoder(prompt, encoder_output=stt.model.encoder(mel)).float().cpu()
+    with torch.no_grad():
+        want, _ = oracle.decoder(torch.from_numpy(prompt).long(), oracle.cross_kv(oracle.encoder(mel.cpu().float())))
+    assert got.shape == want.shape == (1, 3, 512)
+    assert rel_l2(got.numpy(), want.numpy()) < 2e-2
+    res = stt.infer(os.path.join(golden_dir, "audio_test.wav"), lang="en", max_length=20)
+    assert isinstance(res["segments"][0]["text"], str)
