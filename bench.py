@@ -269,10 +269,14 @@ def bench_whisper(args, rank, world):
         for i, w in enumerate(mine):
             pcm[i] = torch.from_numpy(np.random.default_rng(1000 + w).uniform(-1, 1, 480000).astype(np.float32))
 
-        def run_batch(lo, hi, engine=eng, mel_fn=fn):
+        def run_batch(lo, hi, engine=eng, mel_fn=fn, after_encode=None):
             n = hi - lo
             mel = mel_fn(pcm[lo:hi].reshape(-1))[0].view(n, 3000, dims["n_mels"])     # 30 s = 3000 frames exactly
             engine.encode(mel)
+            if after_encode is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                after_encode(ev)
             prompt = np.array([PROMPT] * n, dtype=np.int32)
             return engine.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
                                    early_stopping=False)
@@ -452,16 +456,22 @@ def bench_pipelined(args, dims, weights, eng0, fn0, run_batch, batches, world):
     if not all_ranks_ok(not errors, world):
         raise errors[0] if errors else RuntimeError("another rank failed to set up the pipelined leg")
     starts = np.cumsum([0] + [len(b) for b in batches])
-    first = threading.Event()
+    first, box = threading.Event(), {}
+
+    def encoded(ev):
+        box["event"] = ev
+        first.set()
 
     def worker(r):
         try:
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
-                if r == 1:
+                if r == 1:                  # one phase late: start when the first encoder pass is done
                     first.wait()
+                    if "event" in box:
+                        box["event"].synchronize()
                 for i in range(r, len(batches), 2):
-                    run_batch(int(starts[i]), int(starts[i + 1]), engs[r], fns[r])
-                    first.set()
+                    run_batch(int(starts[i]), int(starts[i + 1]), engs[r], fns[r],
+                              after_encode=encoded if i == 0 else None)
         except BaseException as e:
             errors.append(e)
         finally:

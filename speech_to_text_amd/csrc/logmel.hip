@@ -181,6 +181,8 @@ struct LogmelArgs {
   float* seg_min;        // [n_tiles * 4]
   unsigned* ticket;      // plan-owned, zero between launches
   float* blk_max;        // plan-owned, one slot per block
+  const float* lds_table;  // two-lanes-per-frame kernel: window and twiddle tables copied into LDS
+  float* dbg;              // development aid: per-lane dump of the first tile (null in normal use)
 };
 
 // BULK: the piece is long enough (host-checked: hi_al - origin >= (LM_ROWS + 1) * 160) for the
@@ -397,18 +399,378 @@ void logmel_finalize(float* __restrict__ out, long n_frames, int n_mels, int n_s
   }
 }
 
+
+// =============================================================================================
+// Two lanes per frame (lane l and lane l + 32 of a wave): the state a lane carries through the
+// transform is 200 floats, the kernel fits 256 registers and two waves share a SIMD, so one
+// wave's scalar instructions, waits and hazards issue under the other's arithmetic.  A 256-lane
+// workgroup owns a tile of 118 frames (80 KB of LDS: two workgroups per CU); the dataflow inside
+// a lane pair is described in gen_logmel2.py.
+// =============================================================================================
+__device__ __forceinline__ void lm2_swap(float& vdst, float& src0) {
+  // v_permlane32_swap: vdst of lanes 32..63 <-> src0 of lanes 0..31.  Written as an asm statement
+  // because __builtin_amdgcn_permlane32_swap loses its second result in this compiler (both
+  // elements of the returned pair read the first one); the leading s_nop covers the two wait
+  // states a permlane swap needs after a VALU write of its operands, which the compiler does not
+  // insert in front of an asm statement.
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vdst), "+v"(src0));
+}
+
+// four swaps behind one leading s_nop (the operands of the later ones are older still)
+__device__ __forceinline__ void lm2_swap4(float& v0, float& s0, float& v1, float& s1, float& v2, float& s2,
+                                          float& v3, float& s3) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+      "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
+      : "+v"(v0), "+v"(s0), "+v"(v1), "+v"(s1), "+v"(v2), "+v"(s2), "+v"(v3), "+v"(s3));
+}
+
+// (|A + W B|^2, |A - W B|^2) for two independent (A, B, W): r / i hold (A, B) real / imaginary
+// parts in their two halves, cs = (cos, sin) with W = cos - i sin.  The two sequences are
+// interleaved: a packed result may not be consumed by the very next instruction, and the compiler
+// does not pad hazards inside (or right after) an asm statement.
+__device__ __forceinline__ void lm2_combine2(v2f csa, v2f ra, v2f ia, v2f& ma, v2f csb, v2f rb, v2f ib,
+                                             v2f& mb) {
+  v2f ta, tb, ja, jb;
+  asm("s_nop 0\n\t"
+      "v_pk_mul_f32 %[ta], %[csa], %[ra] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %[tb], %[csb], %[rb] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+      "v_pk_fma_f32 %[ta], %[csa], %[ia], %[ta] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,0,0] neg_hi:[0,0,1]\n\t"
+      "v_pk_fma_f32 %[tb], %[csb], %[ib], %[tb] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,0,0] neg_hi:[0,0,1]\n\t"
+      "v_pk_add_f32 %[ma], %[ra], %[ta] op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[mb], %[rb], %[tb] op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[ja], %[ia], %[ta] op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %[jb], %[ib], %[tb] op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %[ma], %[ma], %[ma]\n\t"
+      "v_pk_mul_f32 %[mb], %[mb], %[mb]\n\t"
+      "v_pk_fma_f32 %[ma], %[ja], %[ja], %[ma]\n\t"
+      "v_pk_fma_f32 %[mb], %[jb], %[jb], %[mb]\n\t"
+      "s_nop 0"
+      : [ma] "=&v"(ma), [mb] "=&v"(mb), [ta] "=&v"(ta), [tb] "=&v"(tb), [ja] "=&v"(ja), [jb] "=&v"(jb)
+      : [csa] "v"(csa), [ra] "v"(ra), [ia] "v"(ia), [csb] "v"(csb), [rb] "v"(rb), [ib] "v"(ib));
+}
+
+#include "logmel2_codelet.inc"
+
+#define LM2_TILE_FRAMES 118
+#define LM2_ROWS (LM2_TILE_FRAMES + 2)
+#define LM2_ROW_BYTES (LM_PITCH * 4)
+#define LM2_TABLE_OFF (LM2_ROWS * LM2_ROW_BYTES)                      // 78720
+#define LM2_LDS_TABLE_BYTES (LOGMEL2_WIN_BYTES + LOGMEL2_TW_BYTES)    // 2912
+#define LM2_LDS_BYTES 81920
+#define LM2_PIECES (LM2_ROWS * LM_CHUNKS_PER_ROW)
+#define LM2_DMA_PER_WAVE ((LM2_PIECES + 255) / 256)
+#define LM2_ROW_DMA_PER_WAVE ((LM2_ROWS + 3) / 4)
+
+// Lane-clamped transfer of a tile's span (see issue_tile_dma); pieces past the last row are not
+// written: the tables live there.
+__device__ __forceinline__ void issue_tile_dma2(const float* __restrict__ pcm, int g0r, int hi_r,
+                                                unsigned char* lds, int wave, int lane) {
+#pragma unroll 4
+  for (int i = 0; i < LM2_DMA_PER_WAVE; ++i) {
+    const int inst = wave + 4 * i;
+    const int q = inst * 64 + lane;
+    const int r = q / LM_CHUNKS_PER_ROW;
+    int cc = q - r * LM_CHUNKS_PER_ROW;
+    cc = cc > 39 ? 39 : cc;
+    int s = g0r + r * LM_HOP + 4 * cc;
+    s = s > hi_r - 4 ? hi_r - 4 : s;
+    s = s < 0 ? 0 : s;
+    if (q < LM2_PIECES)
+      __builtin_amdgcn_global_load_lds((glb_void*)((const char*)pcm + (unsigned)(s * 4)),
+                                       (lds_void*)(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+// One instruction per LDS row (see issue_rows_dma); the last row's instruction keeps the lanes
+// that would spill into the tables switched off.
+__device__ __forceinline__ void issue_rows_dma2(const RowDma& d, int wave, int ln, int i0, int i1) {
+#pragma unroll
+  for (int i = i0; i < i1; ++i) {
+    int di = 4 * i;
+    if (4 * i + 3 >= LM2_ROWS) di = min(di, LM2_ROWS - 1 - wave);
+    const bool last = wave + di == LM2_ROWS - 1;             // wave-uniform
+    if (!last || ln < 41)
+      __builtin_amdgcn_global_load_lds((glb_void*)(d.base + (long)di * (LM_HOP * 4) + d.lane_off),
+                                       (lds_void*)(size_t)(d.lds0 + di * LM2_ROW_BYTES), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void patch_reflect2(const float* __restrict__ pcm, long origin, long n_total,
+                                               long hi_al, long g0, float* lds, int tid) {
+  if (tid < 200) {
+    const long g = -200 + tid;
+    const long i = g - g0;
+    if (i >= 0 && i < (long)LM2_ROWS * LM_HOP) {
+      const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
+      lds[r * LM_PITCH + c] = pcm[-g - origin];
+    }
+  }
+  if (tid < 204) {
+    const long g = hi_al + tid;
+    const long i = g - g0;
+    if (i >= 0 && i < (long)LM2_ROWS * LM_HOP) {
+      const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
+      long src = g < n_total ? g : 2 * (n_total - 1) - g;
+      src = src < origin ? origin : src;
+      lds[r * LM_PITCH + c] = pcm[src - origin];
+    }
+  }
+}
+
+template <int NMELS>
+struct Lm2Shape;
+template <>
+struct Lm2Shape<80> {
+  static constexpr int kSplit = LOGMEL2_SPLIT_80, kAcc = LOGMEL2_NACC_80;
+  static __device__ __forceinline__ void project(float (&mg)[104], lm_const_ptr ct, bool upper, float (&acc)[kAcc]) {
+    logmel2_project_80(mg, ct, upper, acc);
+  }
+};
+template <>
+struct Lm2Shape<128> {
+  static constexpr int kSplit = LOGMEL2_SPLIT_128, kAcc = LOGMEL2_NACC_128;
+  static __device__ __forceinline__ void project(float (&mg)[104], lm_const_ptr ct, bool upper, float (&acc)[kAcc]) {
+    logmel2_project_128(mg, ct, upper, acc);
+  }
+};
+
+template <int NMELS, bool BULK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void logmel_pair(const LogmelArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM2_LDS_BYTES];
+  constexpr int kSplit = Lm2Shape<NMELS>::kSplit, kAcc = Lm2Shape<NMELS>::kAcc;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool upper = lane >= 32;
+  const int slot = 32 * wave + (lane & 31);             // frame of the tile this lane pair owns
+  const lm_const_ptr ct = (lm_const_ptr)(unsigned long long)a.ct;
+
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  const int hi_r = (int)(a.hi_al - a.origin);
+  issue_tile_dma2(a.pcm, (int)((a.frame_begin + (long)tile * LM2_TILE_FRAMES) * LM_HOP - 200 - a.origin),
+                  hi_r, lds, wave, lane);
+  if (tid < LM2_LDS_TABLE_BYTES / 16)
+    *(v4f*)(lds + LM2_TABLE_OFF + 16 * tid) = *(const v4f*)(a.lds_table + 4 * tid);
+  __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
+  __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+
+  const int fslot = slot < LM2_TILE_FRAMES ? slot : LM2_TILE_FRAMES - 1;
+  const unsigned char* base = lds + fslot * LM2_ROW_BYTES + (upper ? 8 : 0);
+  const unsigned char* wt = lds + LM2_TABLE_OFF + (upper ? LOGMEL2_WIN_BYTES / 2 : 0);
+  const unsigned char* tt = lds + LM2_TABLE_OFF + LOGMEL2_WIN_BYTES + (upper ? LOGMEL2_TW_BYTES / 2 : 0);
+
+#ifdef LM_TIMING
+  unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  float run_max = -__builtin_inff();
+  while (tile < a.n_tiles) {
+    const long t0 = a.frame_begin + (long)tile * LM2_TILE_FRAMES;
+    const long g0 = t0 * LM_HOP - 200;
+    __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
+    block_barrier();                        // every wave's DMA pieces of this tile have landed
+    LM_TICK(0)
+    if (g0 < 0 || g0 + (long)(LM2_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
+      if (BULK) {
+        issue_tile_dma2(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane);
+        __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
+        block_barrier();
+      }
+      patch_reflect2(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
+      __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+      block_barrier();
+    }
+
+    v2f sa[LOGMEL2_N_SA];
+    LM_TICK(1)
+    logmel2_pass_a(base, wt, ct, sa);
+    __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
+    LM_TICK(2)
+    block_barrier();                        // the rows may now be refilled
+    LM_TICK(3)
+    const int next = tile + gridDim.x;
+    int g0r_next = (int)((a.frame_begin + (long)next * LM2_TILE_FRAMES) * LM_HOP - 200 - a.origin);
+    if (!BULK && next < a.n_tiles) issue_tile_dma2(a.pcm, g0r_next, hi_r, lds, wave, lane);
+    g0r_next = min(max(g0r_next, 0), hi_r - (LM2_ROWS + 1) * LM_HOP);
+    float mg[104];
+    // The next tile's rows are requested a few at a time after every family (scalar code only,
+    // rebuilt each time so that nothing stays live across the register-starved sections).  Every
+    // workgroup of the chip runs the same phases at about the same time, so a burst of requests
+    // meets everybody else's burst at the memory side and the wave stalls at issue behind a full
+    // queue; thirteen small instalments keep the demand under the CU's share of the HBM rate.
+    logmel2_pass_b(ct, tt, sa, mg, [&](int f) __attribute__((always_inline)) {
+      if (BULK) {
+        RowDma rd;
+        rd.base = (const char*)a.pcm + ((long)g0r_next + wave * LM_HOP) * 4;
+        rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * LM2_ROW_BYTES;
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+        rd.lane_off = ln * 16 - (ln >= 40 ? 16 : 0);
+        issue_rows_dma2(rd, wave, ln, (LM2_ROW_DMA_PER_WAVE * f) / 13, (LM2_ROW_DMA_PER_WAVE * (f + 1)) / 13);
+      }
+    });
+    if (a.dbg && tile == 0) {
+      float* d = a.dbg + tid * 512;
+#pragma unroll
+      for (int i = 0; i < LOGMEL2_N_SA; ++i) { d[2 * i] = sa[i].x; d[2 * i + 1] = sa[i].y; }
+#pragma unroll
+      for (int i = 0; i < 104; ++i) d[200 + i] = mg[i];
+    }
+    LM_TICK(4)
+    float mel[kAcc];
+    Lm2Shape<NMELS>::project(mg, ct, upper, mel);
+#ifdef LM_TIMING
+    asm volatile("" :: "v"(mel[0]), "v"(mel[kAcc - 1]), "v"(mel[7]));
+#endif
+    LM_TICK(5)
+    if (a.dbg && tile == 0) {
+      float* d = a.dbg + tid * 512;
+#pragma unroll
+      for (int i = 0; i < kAcc; ++i) d[304 + i] = mel[i];
+    }
+
+    const long row = (long)tile * LM2_TILE_FRAMES + slot;
+    const bool valid = slot < LM2_TILE_FRAMES && row < a.frame_count;
+    float ymax = -__builtin_inff(), zmin = __builtin_inff();
+#pragma unroll
+    for (int m = 0; m < kAcc; ++m) {
+      // log10 = log2 x log10(2), as __log10f computes it; its denormal pre-scaling is left out (the
+      // argument is at least 1e-10)
+      const float y = __builtin_amdgcn_logf(fmaxf(mel[m], 1e-10f)) * 0.3010299956639812f;
+      ymax = fmaxf(ymax, y);
+      const float z = (y + 4.0f) * 0.25f;
+      zmin = fminf(zmin, z);
+      mel[m] = z;
+    }
+    if (!valid) {
+      ymax = -__builtin_inff();
+      zmin = __builtin_inff();
+    }
+#ifdef LM_TIMING
+    asm volatile("" :: "v"(zmin), "v"(ymax), "v"(mel[0]), "v"(mel[kAcc - 1]));
+#endif
+    LM_TICK(6)
+    LM_TICK(8)
+    // Store: the lower lane of a pair holds columns [0, kSplit) of its frame's row, the upper lane
+    // the rest.  Four neighbouring lanes (four consecutive frames, same half) transpose 4 x 4
+    // 16-byte pieces so that a store instruction writes 64 contiguous bytes per quad.
+    {
+      const bool hi1 = lane & 1, hi2 = lane & 2;
+      const long qrow = row - (lane & 3);
+      const int qslot = slot & ~3;
+      const int my_cols = upper ? NMELS - kSplit : kSplit;
+#pragma unroll
+      for (int g = 0; g < kAcc; g += 16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float* r0 = &mel[g + c];
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const float send = hi1 ? r0[4 * j] : r0[4 * (j + 1)];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+                __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+            if (hi1) r0[4 * j] = recv; else r0[4 * (j + 1)] = recv;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float send = hi2 ? r0[4 * j] : r0[4 * (j + 2)];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+                __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+            if (hi2) r0[4 * j] = recv; else r0[4 * (j + 2)] = recv;
+          }
+        }
+      }
+#ifdef LM_TIMING
+      asm volatile("" :: "v"(mel[0]), "v"(mel[kAcc - 1]), "v"(mel[5]));
+#endif
+      LM_TICK(9)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (qslot + j < LM2_TILE_FRAMES && qrow + j < a.frame_count) {
+          float* dst = a.out + (qrow + j) * NMELS + (upper ? kSplit : 0) + 4 * (lane & 3);
+#pragma unroll
+          for (int g = 0; g < kAcc; g += 16)
+            if (g < my_cols)
+              *(v4f*)(dst + g) = v4f{mel[g + 4 * j], mel[g + 4 * j + 1], mel[g + 4 * j + 2], mel[g + 4 * j + 3]};
+        }
+      }
+    }
+    run_max = fmaxf(run_max, ymax);
+    zmin = wave_min(zmin);
+    if (lane == 0) a.seg_min[tile * 4 + wave] = zmin;
+    tile = next;
+    LM_TICK(7)
+  }
+#ifdef LM_TIMING
+  if (blockIdx.x == 7 && lane == 0)
+    printf("wave %d: top wait+barrier %u  edge %u  passA %u  barrier %u  families %u  project %u  log %u  dma issue %u  transposes %u  stores %u\n",
+           wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[8], tacc[9], tacc[7]);
+#endif
+  run_max = wave_max(run_max);
+  block_barrier();
+  float* red = (float*)lds;
+  if (lane == 0) red[wave] = run_max;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __hip_atomic_store(a.blk_max + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[4] = t == gridDim.x - 1 ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (red[4] != 0.0f && wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float m = -__builtin_inff();
+    for (int i = lane; i < (int)gridDim.x; i += 64)
+      m = fmaxf(m, __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    m = wave_max(m);
+    if (lane == 0) {
+      *a.piece_max = m;
+      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Segment s = (tile, wave) covers rows [tile * 118 + 32 * wave, + 32) of that tile.
+__global__ __launch_bounds__(256)
+void logmel_finalize2(float* __restrict__ out, long n_frames, int n_mels, int n_segments,
+                      const float* __restrict__ gmax, const float* __restrict__ seg_min) {
+  const float zc = ((*gmax - 8.0f) + 4.0f) * 0.25f;
+  for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+    if (!(seg_min[s] < zc)) continue;
+    const int tile = s >> 2, wave = s & 3;
+    long r0 = (long)tile * LM2_TILE_FRAMES + 32 * wave;
+    long r1 = r0 + 32;
+    const long tile_end = (long)(tile + 1) * LM2_TILE_FRAMES;
+    r1 = r1 > tile_end ? tile_end : r1;
+    r1 = r1 > n_frames ? n_frames : r1;
+    const long e0 = r0 * n_mels, e1 = r1 * n_mels;
+    for (long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * 256) {
+      v4f v = *(v4f*)(out + e);
+      v.x = fmaxf(v.x, zc); v.y = fmaxf(v.y, zc); v.z = fmaxf(v.z, zc); v.w = fmaxf(v.w, zc);
+      *(v4f*)(out + e) = v;
+    }
+  }
+}
+
 __global__ void logmel_init(float* piece_max) { *piece_max = -__builtin_inff(); }
 
 // ------------------------------------------------------------------ host side
 #include "../../include/stt_mi355x.h"
 #include "logmel_tables.h"
+#include "logmel2_tables.h"
 #include "stt_common.h"
+#include <cstdlib>
 
 struct stt_logmel_plan {
   int n_mels;
   int device;
   int n_cu;
   float* d_table;
+  float* d_table2;       // two-lanes-per-frame kernel: DFT constants + mel weights (scalar loads)
+  float* d_lds_table;    // ... and the window / twiddle tables it copies into LDS
   unsigned* d_sync;      // [0] ticket counter, [64..] one float per block; zeroed at creation
   void* d_static_ws;     // this device's copy of lm_static_ws (address looked up at creation)
 };
@@ -424,11 +786,22 @@ static __device__ __align__(256) unsigned char lm_static_ws[LM_STATIC_WS_BYTES];
 static const size_t kWsHeader = 256;      // piece maximum lives in the first float
 static const size_t kWsPadPcm = 512 * sizeof(float);
 
+// STT_MI355X_LOGMEL=pair selects the two-lanes-per-frame kernel (under development: parity-green,
+// not yet faster than the one-lane-per-frame kernel)
+static bool lm_pair() {
+  static const bool v = getenv("STT_MI355X_LOGMEL") && getenv("STT_MI355X_LOGMEL")[0] == 'p';
+  return v;
+}
+static int tile_frames() { return lm_pair() ? LM2_TILE_FRAMES : LM_TILE_FRAMES; }
 static int tiles_for(int64_t frames) {
-  return (int)((frames + LM_TILE_FRAMES - 1) / LM_TILE_FRAMES);
+  return (int)((frames + tile_frames() - 1) / tile_frames());
 }
 
+static float* g_lm_debug = nullptr;
+
 extern "C" {
+
+void stt_logmel_set_debug(float* d_buffer) { g_lm_debug = d_buffer; }    // development aid, not in the header
 
 int64_t stt_logmel_num_frames(int64_t n_samples) {
   if (n_samples < LM_NFFT) n_samples = LM_NFFT;
@@ -476,6 +849,23 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
   for (int i = 0; i < nnz; ++i)
     table[off_mel + i] = mel_basis[(size_t)nz[i][0] * n_mels + nz[i][1]];
 
+  // tables of the two-lanes-per-frame kernel
+  const int nnz2 = n_mels == 80 ? LOGMEL2_NNZ_80 : LOGMEL2_NNZ_128;
+  const unsigned short (*nz2)[2] = n_mels == 80 ? logmel2_nz_80 : logmel2_nz_128;
+  const int off_mel2 = n_mels == 80 ? LOGMEL2_OFF_MEL80 : LOGMEL2_OFF_MEL128;
+  std::vector<float> table2((LOGMEL2_TABLE_LEN + 3) & ~3, 0.0f);      // the LDS tables behind it stay 16-byte aligned
+  for (int i = 0; i < LOGMEL2_N_FFT_CONSTS; ++i) table2[LOGMEL2_OFF_FFT + i] = logmel2_fft_consts[i];
+  for (int i = 0; i < nnz2; ++i) table2[off_mel2 + i] = mel_basis[(size_t)nz2[i][0] * n_mels + nz2[i][1]];
+  std::vector<float> lds_table(LM2_LDS_TABLE_BYTES / 4, 0.0f);
+  for (int half = 0; half < 2; ++half)
+    for (int j = 0; j < 4; ++j)
+      for (int pos = 0; pos < 25; ++pos) {         // pairs in the order the sub-DFT consumes them
+        const int m = j + 4 * logmel2_win_pos[j][pos], at = 2 * (half * 104 + 26 * j + pos);
+        lds_table[at] = window[4 * m + 2 * half];
+        lds_table[at + 1] = window[4 * m + 2 * half + 1];
+      }
+  for (int i = 0; i < LOGMEL2_TW_BYTES / 4; ++i) lds_table[LOGMEL2_WIN_BYTES / 4 + i] = logmel2_twiddles[i];
+
   stt_logmel_plan* p = new stt_logmel_plan();
   p->n_mels = n_mels;
   STT_HIP_OR_FAIL(hipGetDevice(&p->device), delete p);
@@ -485,7 +875,16 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
   STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table, table.size() * sizeof(float)), delete p);
   STT_HIP_OR_FAIL(hipMemcpy(p->d_table, table.data(), table.size() * sizeof(float),
                             hipMemcpyHostToDevice), ((void)hipFree(p->d_table), delete p));
-  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4), ((void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table2, (table2.size() + lds_table.size()) * sizeof(float)),
+                  ((void)hipFree(p->d_table), delete p));
+  p->d_lds_table = p->d_table2 + table2.size();
+  STT_HIP_OR_FAIL(hipMemcpy(p->d_table2, table2.data(), table2.size() * sizeof(float), hipMemcpyHostToDevice),
+                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMemcpy(p->d_lds_table, lds_table.data(), lds_table.size() * sizeof(float),
+                            hipMemcpyHostToDevice),
+                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4),
+                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
   STT_HIP_OR_FAIL(hipMemset(p->d_sync, 0, (64 + 1024) * 4),
                   ((void)hipFree(p->d_sync), (void)hipFree(p->d_table), delete p));
   // the plan belongs to the current device: look up that device's copy of the static workspace
@@ -498,6 +897,7 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
 void stt_logmel_plan_destroy(stt_logmel_plan* plan) {
   if (!plan) return;
   (void)hipFree(plan->d_table);
+  (void)hipFree(plan->d_table2);
   (void)hipFree(plan->d_sync);
   delete plan;
 }
@@ -550,6 +950,25 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
   a.ct = plan->d_table; a.out = d_mel; a.piece_max = d_piece_max;
   a.seg_min = (float*)((char*)d_workspace + kWsHeader);
   a.ticket = plan->d_sync; a.blk_max = (float*)(plan->d_sync + 64);
+  if (lm_pair()) {
+    a.ct = plan->d_table2;
+    a.lds_table = plan->d_lds_table;
+    a.dbg = g_lm_debug;
+    int grid = n_tiles < 2 * plan->n_cu ? n_tiles : 2 * plan->n_cu;      // two workgroups per CU
+    grid = grid < 1024 ? grid : 1024;
+    const bool bulk = a.hi_al - a.origin >= (long)(LM2_ROWS + 1) * LM_HOP;
+    if (plan->n_mels == 80) {
+      if (bulk) hipLaunchKernelGGL((logmel_pair<80, true>), dim3(grid), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((logmel_pair<80, false>), dim3(grid), dim3(256), 0, stream, a);
+    } else {
+      if (bulk) hipLaunchKernelGGL((logmel_pair<128, true>), dim3(grid), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((logmel_pair<128, false>), dim3(grid), dim3(256), 0, stream, a);
+    }
+    STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+    return STT_OK;
+  }
+  a.lds_table = nullptr;
+  a.dbg = nullptr;
   int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
   grid = grid < 1024 ? grid : 1024;
   const bool bulk = a.hi_al - a.origin >= (long)(LM_ROWS + 1) * LM_HOP;
@@ -572,9 +991,14 @@ int stt_logmel_stage2(const stt_logmel_plan* plan, float* d_mel, int64_t frame_c
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   const int n_seg = tiles_for(frame_count) * 4;
   const int grid = n_seg < 2048 ? n_seg : 2048;
-  hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
-                     plan->n_mels, n_seg, d_clip_max,
-                     (const float*)((const char*)d_workspace + kWsHeader));
+  if (lm_pair())
+    hipLaunchKernelGGL(logmel_finalize2, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
+                       plan->n_mels, n_seg, d_clip_max,
+                       (const float*)((const char*)d_workspace + kWsHeader));
+  else
+    hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
+                       plan->n_mels, n_seg, d_clip_max,
+                       (const float*)((const char*)d_workspace + kWsHeader));
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
 }
@@ -609,7 +1033,7 @@ int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_sa
 int64_t stt_logmel_static_max_samples(void) {
   // largest n with stt_logmel_workspace_bytes(n) <= LM_STATIC_WS_BYTES
   const int64_t tiles = (int64_t)(LM_STATIC_WS_BYTES - kWsHeader - kWsPadPcm) / (4 * sizeof(float)) / 64 * 64;
-  return tiles * LM_TILE_FRAMES * LM_HOP;
+  return tiles * tile_frames() * LM_HOP;
 }
 
 int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,

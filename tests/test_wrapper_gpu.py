@@ -54,10 +54,15 @@ def test_detect_language(model, golden_dir):
     with torch.no_grad():
         logits, _ = oracle.decoder(torch.tensor([[model.sos_token_idx]]), oracle.cross_kv(oracle.encoder(mel)))
     want_lang, want = osg.detect_language(logits[0, -1].numpy(), model.language_indexes, model.languages)
+    # a probability moves by about the logit error as a fraction of itself; the allowance for a
+    # logit is tests/_parity.py's 0.04 x the spread of the row (bf16 storage)
+    from tests._parity import MARGIN_REL
+    row = logits[0, -1].numpy()[model.language_indexes]
+    allow = float(np.expm1(2 * MARGIN_REL * row.std()))
     diff = max(abs(probs[k] - want[k]) for k in want)
-    assert diff < 0.02 * max(want.values()) + 1e-4, diff
+    assert diff < allow * max(want.values()) + 1e-4, (diff, allow)
     ranked = sorted(want.values())
-    assert lang == want_lang or ranked[-1] - ranked[-2] < 0.02 * ranked[-1]
+    assert lang == want_lang or ranked[-1] - ranked[-2] < allow * ranked[-1]
 
 
 def test_window_batching_is_batch_invariant(model):
