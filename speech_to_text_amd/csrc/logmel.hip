@@ -537,7 +537,10 @@ struct Lm2Shape<128> {
 template <int NMELS, bool BULK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logmel_pair(const LogmelArgs a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM2_LDS_BYTES];
+  // two objects, so that the compiler does not order the table reads of the second pass behind
+  // the transfers that refill the rows (it would wait for every instalment to land)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM2_TABLE_OFF];
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[LM2_LDS_TABLE_BYTES];
   constexpr int kSplit = Lm2Shape<NMELS>::kSplit, kAcc = Lm2Shape<NMELS>::kAcc;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -552,14 +555,14 @@ void logmel_pair(const LogmelArgs a) {
   issue_tile_dma2(a.pcm, (int)((a.frame_begin + (long)tile * LM2_TILE_FRAMES) * LM_HOP - 200 - a.origin),
                   hi_r, lds, wave, lane);
   if (tid < LM2_LDS_TABLE_BYTES / 16)
-    *(v4f*)(lds + LM2_TABLE_OFF + 16 * tid) = *(const v4f*)(a.lds_table + 4 * tid);
+    *(v4f*)(tabs + 16 * tid) = *(const v4f*)(a.lds_table + 4 * tid);
   __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
   __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
 
   const int fslot = slot < LM2_TILE_FRAMES ? slot : LM2_TILE_FRAMES - 1;
   const unsigned char* base = lds + fslot * LM2_ROW_BYTES + (upper ? 8 : 0);
-  const unsigned char* wt = lds + LM2_TABLE_OFF + (upper ? LOGMEL2_WIN_BYTES / 2 : 0);
-  const unsigned char* tt = lds + LM2_TABLE_OFF + LOGMEL2_WIN_BYTES + (upper ? LOGMEL2_TW_BYTES / 2 : 0);
+  const unsigned char* wt = tabs + (upper ? LOGMEL2_WIN_BYTES / 2 : 0);
+  const unsigned char* tt = tabs + LOGMEL2_WIN_BYTES + (upper ? LOGMEL2_TW_BYTES / 2 : 0);
 
 #ifdef LM_TIMING
   unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -595,21 +598,22 @@ void logmel_pair(const LogmelArgs a) {
     if (!BULK && next < a.n_tiles) issue_tile_dma2(a.pcm, g0r_next, hi_r, lds, wave, lane);
     g0r_next = min(max(g0r_next, 0), hi_r - (LM2_ROWS + 1) * LM_HOP);
     float mg[104];
-    // The next tile's rows are requested a few at a time after every family (scalar code only,
-    // rebuilt each time so that nothing stays live across the register-starved sections).  Every
-    // workgroup of the chip runs the same phases at about the same time, so a burst of requests
-    // meets everybody else's burst at the memory side and the wave stalls at issue behind a full
-    // queue; thirteen small instalments keep the demand under the CU's share of the HBM rate.
+    // The next tile's rows are requested in four instalments between the families (scalar code
+    // only, rebuilt each time so that nothing stays live across the register-starved sections).
     logmel2_pass_b(ct, tt, sa, mg, [&](int f) __attribute__((always_inline)) {
-      if (BULK) {
+      constexpr int kEvery = 13 / LM_DMA_PARTS;
+      if (BULK && f % kEvery == 0 && f / kEvery < LM_DMA_PARTS) {
+        const int part = f / kEvery;
         RowDma rd;
         rd.base = (const char*)a.pcm + ((long)g0r_next + wave * LM_HOP) * 4;
         rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * LM2_ROW_BYTES;
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
         rd.lane_off = ln * 16 - (ln >= 40 ? 16 : 0);
-        issue_rows_dma2(rd, wave, ln, (LM2_ROW_DMA_PER_WAVE * f) / 13, (LM2_ROW_DMA_PER_WAVE * (f + 1)) / 13);
+        issue_rows_dma2(rd, wave, ln, (LM2_ROW_DMA_PER_WAVE * part) / LM_DMA_PARTS,
+                        (LM2_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
       }
     });
+#ifdef LM2_DEBUG       // development build only: keeps all of sa alive through the second pass
     if (a.dbg && tile == 0) {
       float* d = a.dbg + tid * 512;
 #pragma unroll
@@ -617,6 +621,7 @@ void logmel_pair(const LogmelArgs a) {
 #pragma unroll
       for (int i = 0; i < 104; ++i) d[200 + i] = mg[i];
     }
+#endif
     LM_TICK(4)
     float mel[kAcc];
     Lm2Shape<NMELS>::project(mg, ct, upper, mel);
@@ -624,11 +629,13 @@ void logmel_pair(const LogmelArgs a) {
     asm volatile("" :: "v"(mel[0]), "v"(mel[kAcc - 1]), "v"(mel[7]));
 #endif
     LM_TICK(5)
+#ifdef LM2_DEBUG
     if (a.dbg && tile == 0) {
       float* d = a.dbg + tid * 512;
 #pragma unroll
       for (int i = 0; i < kAcc; ++i) d[304 + i] = mel[i];
     }
+#endif
 
     const long row = (long)tile * LM2_TILE_FRAMES + slot;
     const bool valid = slot < LM2_TILE_FRAMES && row < a.frame_count;
