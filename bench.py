@@ -168,7 +168,7 @@ def bench_logmel(args, rank, world, steps, warmup):
     alg_bytes = n * 4 + frames * args.n_mels * 4          # each sample read once, each mel written once
     value = world * steps * alg_bytes / dt / 1e9           # GB/s, whole job
 
-    # dominant kernel (logmel_main), timed with events on the launching stream
+    # dominant kernel (logmel_pair), timed with events on the launching stream
     piece_max = ws[:4].view(torch.float32)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(steps)]
@@ -181,7 +181,7 @@ def bench_logmel(args, rank, world, steps, warmup):
     torch.cuda.synchronize()
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "logmel_main<%d>" % args.n_mels, "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "logmel_pair<%d>" % args.n_mels, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_note": "HBM bytes cannot be read from inside the process: see "
                 "the rocprofv3 --pmc passes under profiles/ (FETCH_SIZE / WRITE_SIZE) for this kernel",

@@ -63,7 +63,7 @@ int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_sa
 
 /* stt_logmel_run without the workspace argument and without any allocation, for callers that
  * cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that
- * forbid it).  No counterpart in the reference.  The workspace is a 64 KiB array inside the
+ * forbid it).  No counterpart in the reference.  The workspace is a 128 KiB array inside the
  * library's code object (one copy per GPU, held until the process ends), which limits the clip
  * to stt_logmel_static_max_samples() samples (about 2.6 h at 16 kHz); longer clips get
  * STT_ERR_WORKSPACE.  The plan must have been created on the current device.  All calls on one

@@ -1,28 +1,28 @@
 #!/usr/bin/env python3
-"""Generates the straight-line per-frame log-mel codelet for the HIP frontend.
+"""Generates the straight-line log-mel codelet in which TWO lanes share one 400-sample frame.
 
-One GPU lane computes one 400-sample frame entirely in registers.  The frame is
-viewed as two interleaved real sequences e[n] = x[2n], o[n] = x[2n+1]
-(n = 0..199) held in the two halves of a packed-float register pair, so that a
-single real-input 200-point DFT program runs on both at once with packed
-arithmetic and wave-uniform scalar constants only:
+A frame is viewed as two interleaved real sequences e[n] = x[2n], o[n] = x[2n+1] (n = 0..199)
+held in the two halves of a packed-float register pair, and that packed sequence s[n] is decimated once more across a lane pair
+(lane l and lane l + 32 of a wave):
 
-    X[k]       = E[k] + W400^k O[k]             k = 0..100
-    |X[200-k]| = |E[k] - W400^k O[k]|           k = 0..99
+    lane half p computes the real 100-point DFT  S_p[k] of s[2m + p], m = 0..99   (k = 0..50)
+    S[k]       = S_0[k] + W200^k S_1[k]
+    S[100 - k] = conj(S_0[k] - W200^k S_1[k])
+    X[k]       = E[k] + W400^k O[k],   |X[200-k]| = |E[k] - W400^k O[k]|     (E, O = halves of S)
 
-The 200-point real DFT is radix 8 x 25 (25 = 5 x 5): eight real 25-point DFTs
-over n2 (n = n1 + 8 n2), a twiddle, then 8-point complex DFTs over n1 for the
-13 residues k2 = 0..12; Hermitian symmetry supplies the rest.
-
-The program is built as an SSA graph over real values with zero/sign folding,
-common-subexpression elimination and dead-code elimination, checked against
-numpy's FFT, and written out as C++ on ``v2f`` (ext_vector_type(2) float).
-Every constant (twiddles, window, mel weights) is read from one float table so
-that the compiler fetches them with batched scalar loads.
+so that the state a lane carries between the passes is 200 floats instead of 400 and two waves
+fit on a SIMD.  The 100-point real DFT is radix 4 x 25 (25 = 5 x 5).  After family k2 of the
+second pass has produced S_p[k] for k in {k2, 25-k2, 25+k2, 50-k2}, one v_permlane32_swap per
+float leaves (S_0[kappa], S_1[kappa]) in the lower lanes for kappa <= 25 and in the upper lanes
+for kappa = 50 - k (>= 25): each lane then finishes its own kappa with per-lane twiddles read
+from a small LDS table and ends up with |X| of the four bins kappa, 200-kappa, 100-kappa,
+100+kappa.  The mel projection is two programs, one per lane half (filters below / from SPLIT),
+run one after the other under the half's execution mask; the magnitudes a half needs but does
+not own are exchanged with the same swap instruction first.
 
 Outputs (next to this file):
     logmel_codelet.inc   device code
-    logmel_tables.h      host-side description of the constant table
+    logmel_tables.h      host-side description of the tables
 """
 import math
 import os
@@ -33,10 +33,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from speech_to_text_amd.audio.mel_basis import mel_filterbank  # noqa: E402
-
-N_FFT = 400
-NH = 200          # length of each interleaved real sequence
-
 
 # --------------------------------------------------------------------------
 # SSA graph over real values
@@ -232,31 +228,6 @@ def rdft(x, radices):
 # --------------------------------------------------------------------------
 # build + check + emit
 # --------------------------------------------------------------------------
-def build_fft():
-    """Top level written out (radix 8 over n1) so that the two passes are visible."""
-    g = Graph()
-    xs = [R(g, g.node("in", i)) for i in range(NH)]
-    r, m, n = 8, 25, NH
-    subs = [rdft(xs[j::r], [5, 5]) for j in range(r)]
-
-    def sub_bin(j, k2):
-        return subs[j][k2] if k2 <= m // 2 else subs[j][m - k2].conj()
-
-    fams = {}
-    for k2 in range(m // 2 + 1):
-        t = [sub_bin(j, k2).mul_const(_w(n, j * k2)) for j in range(r)]
-        fams[k2] = dft(t)
-    bins = []
-    for k in range(n // 2 + 1):
-        k2 = k % m
-        if k2 <= m // 2:
-            bins.append(fams[k2][k // m])
-        else:
-            kk = n - k
-            bins.append(fams[kk % m][kk // m].conj())
-    return g, bins, subs, fams
-
-
 def live_nodes(g, roots):
     live = set()
     stack = [r for r in roots if r is not None]
@@ -290,365 +261,147 @@ def evaluate(g, live, inputs):
     return val
 
 
-def self_check(g, bins, live):
-    rng = np.random.default_rng(1)
-    x = rng.standard_normal(NH)
-    val = evaluate(g, live, x)
-
-    def get(r):
-        return 0.0 if r.zero else r.s * val[r.n]
-    got = np.array([complex(get(b.re), get(b.im)) for b in bins])
-    ref = np.fft.rfft(x)
-    err = np.abs(got - ref).max()
-    assert err < 2e-5, "generated DFT disagrees with numpy: %g" % err
-    return err
+N_FFT = 400
+NL = 100                   # length of the packed sequence one lane transforms
+SPLIT = {80: 48, 128: 64}  # first filter of the upper half's projection program
 
 
-def rname(r):
-    if r.zero:
-        return "v2f{0.f, 0.f}"
-    return ("-" if r.s < 0 else "") + "t%d" % r.n
+def build_fft():
+    g = Graph()
+    xs = [R(g, g.node("in", i)) for i in range(NL)]
+    r, m, n = 4, 25, NL
+    subs = [rdft(xs[j::r], [5, 5]) for j in range(r)]
+
+    def sub_bin(j, k2):
+        return subs[j][k2] if k2 <= m // 2 else subs[j][m - k2].conj()
+
+    fams = {}
+    for k2 in range(m // 2 + 1):
+        t = [sub_bin(j, k2).mul_const(_w(n, j * k2)) for j in range(r)]
+        fams[k2] = dft(t)
+    bins = []
+    for k in range(n // 2 + 1):
+        k2 = k % m
+        if k2 <= m // 2:
+            bins.append(fams[k2][k // m])
+        else:
+            kk = n - k
+            bins.append(fams[kk % m][kk // m].conj())
+    return g, bins, subs
 
 
-def mel_structure(n_mels):
-    """[(bin, filter)] of the non-zeros of the Whisper filterbank, per filter in
-    ascending bin order (the summation order of a dense matmul row)."""
+def kappa_slots():
+    """[(family, kappa of the lower half, kappa of the upper half or None)] in generation order."""
+    slots = [(0, 0, 50), (0, 25, None)]
+    for f in range(1, 13):
+        slots += [(f, f, 50 - f), (f, 25 - f, 25 + f)]
+    return slots
+
+
+def bins_of(kappa):
+    return [kappa, 200 - kappa, 100 - kappa, 100 + kappa]
+
+
+def twiddles(kappa):
+    """(cos, sin) pairs a lane needs for its kappa: W200^kappa, then the E/O twiddle of S[kappa]
+    and of conj(S[100 - kappa]) (conjugated, so the same instruction sequence serves both)."""
+    a = 2 * math.pi * kappa / 200
+    b = 2 * math.pi * kappa / 400
+    c = 2 * math.pi * (100 - kappa) / 400
+    return [(math.cos(a), math.sin(a)), (math.cos(b), math.sin(b)), (math.cos(c), -math.sin(c))]
+
+
+def exchange_plan(n_mels):
+    """Which magnitude registers the two halves swap before the projection.
+
+    Register mg[4 i + c] holds bin bins_of(kappa)[c] of the half's i-th kappa.  Returns
+    (moves, loc_lower, loc_upper, pairs_lower, pairs_upper): moves = [(vdst, src0, copy_vdst,
+    copy_src0)] register indices for lm_swap (upper's vdst <-> lower's src0; a copy flag says
+    the register is duplicated into a scratch register first because its owner still needs it),
+    loc_* = bin -> register name after the moves."""
     fb = mel_filterbank(16000, N_FFT, n_mels, 0.0, 8000.0)
-    pairs = []
+    split = SPLIT[n_mels]
+    pairs = [[], []]
     for m in range(n_mels):
         ks = np.nonzero(fb[:, m])[0]
         assert len(ks) > 0 and (np.diff(ks) == 1).all()
         for k in ks:
-            pairs.append((int(k), m))
-    return pairs
-
-
-def park_name(slot):
-    return "ag[%d]" % slot
-
-
-def main():
-    g, bins, subs, fams = build_fft()
-    roots = []
-    for b in bins:
-        roots += [b.re.n, b.im.n]
-    live = live_nodes(g, roots)
-    err = self_check(g, bins, live)
-
-    # ---- pass A: the eight 25-point real sub-DFTs; their outputs are the boundary
-    boundary = {}            # node -> ("ag", slot) | ("sv", slot)
-    sub_nodes = []
-    n_ag = n_sv = 0
-    for j in range(8):
-        rts = []
-        for b in subs[j]:
-            rts += [b.re.n, b.im.n]
-        nodes = sorted(live_nodes(g, rts) & live)
-        sub_nodes.append(nodes)
-        for n in sorted(set(r for r in rts if r is not None) & live):
-            if n in boundary:
-                continue
-            if j < N_SUBS_IN_AGPR:
-                boundary[n] = ("ag", n_ag)
-                n_ag += 2
-            else:
-                boundary[n] = ("sv", n_sv)
-                n_sv += 1
-    pass_a_nodes = set(n for nodes in sub_nodes for n in nodes)
-
-    n_fft_consts_holder = [None]
-
-    out = []
-    emit = out.append
-
-    def emit_node(n, names):
-        op, a, b, c = g.nodes[n]
-        if op == "add":
-            emit("  const v2f t%d = %s + %s;" % (n, names(a), names(b)))
-        elif op == "sub":
-            emit("  const v2f t%d = %s - %s;" % (n, names(a), names(b)))
-        elif op == "mul":
-            emit("  const v2f t%d = %s * ct[%d];" % (n, names(a), OFF_FFT + c))
-
-    # constant table layout (floats)
-    OFF_FFT = 0
-    body_a = []
-    emit = body_a.append
-
-    def emit_ins(j, loader):
-        """Window multiplies of sub-DFT j.  loader(n2) -> C++ expression of the raw v2f pair."""
-        for n in sub_nodes[j]:
-            if g.nodes[n][0] != "in":
-                continue
-            a = g.nodes[n][1]
-            n2 = (a - j) // 8
-            # the window table is stored in the order pass A consumes it (sub-DFT j, then
-            # input n2), so one sub-DFT's 50 values are a few wide scalar loads
-            pos = 2 * (25 * (a % 8) + a // 8)
-            emit("  const v2f t%d = %s * v2f{ct[OFF_WIN + %d], ct[OFF_WIN + %d]};"
-                 % (n, loader(n2), pos, pos + 1))
-
-    def emit_ops(j):
-        nodes = sub_nodes[j]
-        for n in nodes:
-            if g.nodes[n][0] != "in":
-                emit(_fmt_node(g, n, OFF_FFT))
-        for n in nodes:
-            if n in boundary:
-                kind, slot = boundary[n]
-                if kind == "ag":
-                    emit("  ag[%d] = park(t%d.x); ag[%d] = park(t%d.y);" % (slot, n, slot + 1, n))
-                else:
-                    emit("  sv[%d] = t%d;" % (slot, n))
-
-    def lds_off(nn):
-        return (nn // 160) * (164 * 4) + (nn % 160) * 4
-
-    def emit_loads(r):
-        item = PASS_A_ORDER[r]
-        if isinstance(item, tuple):
-            for n2 in range(25):
-                emit("  const v4f q%d_%d = *(const v4f*)(base + %d);"
-                     % (r, n2, lds_off(2 * (item[0] + 8 * n2))))
+            pairs[0 if m < split else 1].append((int(k), m))
+    need = [sorted({k for k, _ in pairs[h]}) for h in (0, 1)]
+    own = [{}, {}]
+    for i, (_, kl, ku) in enumerate(kappa_slots()):
+        for c, b in enumerate(bins_of(kl)):
+            own[0].setdefault(b, 4 * i + c)
+        if ku is not None:
+            for c, b in enumerate(bins_of(ku)):
+                own[1].setdefault(b, 4 * i + c)
+    loc = [{b: "mg[%d]" % own[0][b] for b in need[0] if b in own[0]},
+           {b: "mg[%d]" % own[1][b] for b in need[1] if b in own[1]}]
+    to_lower = [b for b in need[0] if b not in own[0]]       # owned by the upper half
+    to_upper = [b for b in need[1] if b not in own[1]]       # owned by the lower half
+    used = [set(own[0][b] for b in need[0] if b in own[0]), set(own[1][b] for b in need[1] if b in own[1])]
+    # registers whose content the half itself does not need: free to receive
+    free = [[r for r in range(104) if r not in used[0]], [r for r in range(104) if r not in used[1]]]
+    moves, n_tmp = [], 0
+    while to_lower or to_upper:
+        a = to_lower.pop(0) if to_lower else None            # upper -> lower
+        b = to_upper.pop(0) if to_upper else None            # lower -> upper
+        # vdst: the register whose UPPER copy is sent (holds a) and receives b in the upper half
+        # src0: the register whose LOWER copy is sent (holds b) and receives a in the lower half
+        if a is not None:
+            vdst = own[1][a]
+            copy_v = vdst in used[1]                          # the upper half needs bin a itself
         else:
-            for n2 in range(25):
-                emit("  const v2f q%d_%d = *(const v2f*)(base + %d);"
-                     % (r, n2, lds_off(2 * (item + 8 * n2))))
-
-    # LM_PREFETCH_A=1 issues the LDS reads of a region while the previous region's last sub-DFT
-    # is still in its butterflies (its inputs are consumed by then, so the registers are free).
-    # Measured null (166 vs 167 us per hour of audio): LDS reads and scalar loads share one
-    # counter, and the wait for the next window values drains the prefetch anyway.
-    prefetch = os.environ.get("LM_PREFETCH_A", "0") == "1"
-    emit_loads(0)
-    for r, item in enumerate(PASS_A_ORDER):
-        if isinstance(item, tuple):
-            jj = item[0]
-            units = [(jj, lambda n2, r=r: "v2f{q%d_%d.x, q%d_%d.y}" % (r, n2, r, n2)),
-                     (jj + 1, lambda n2, r=r: "v2f{q%d_%d.z, q%d_%d.w}" % (r, n2, r, n2))]
+            vdst = next((r for r in free[1] if r not in [m[0] for m in moves]), None)
+            copy_v = False
+        if b is not None:
+            src0 = own[0][b]
+            copy_s = src0 in used[0]
         else:
-            units = [(item, lambda n2, r=r: "q%d_%d" % (r, n2))]
-        for u, (j, loader) in enumerate(units):
-            emit("  // sub-DFT %d" % j)
-            emit_ins(j, loader)
-            if u == len(units) - 1 and r + 1 < len(PASS_A_ORDER):
-                if prefetch:
-                    emit("  __builtin_amdgcn_sched_barrier(0);")
-                    emit_loads(r + 1)
-                    emit("  __builtin_amdgcn_sched_barrier(0);")
-                    emit_ops(j)
-                else:
-                    emit_ops(j)
-                    emit("  __builtin_amdgcn_sched_barrier(0);")
-                    emit_loads(r + 1)
-            else:
-                emit_ops(j)
-            emit("  __builtin_amdgcn_sched_barrier(0);")
-
-    # ---- pass B: families k2 = 0..12
-    body_b = []
-    emit = body_b.append
-    fam_of_bin = {}
-    for k in range(101):
-        k2 = k % 25
-        fam_of_bin.setdefault(min(k2, 25 - k2), []).append(k)
-    emitted = set(pass_a_nodes)
-    for k2 in range(13):
-        rts = []
-        for k in fam_of_bin[k2]:
-            rts += [bins[k].re.n, bins[k].im.n]
-        nodes = sorted((live_nodes(g, rts) & live) - emitted)
-        emitted |= set(nodes)
-        used_boundary = set()
-        for n in nodes:
-            op, a, b, c = g.nodes[n]
-            for x in (a, b):
-                if x is not None and x in boundary:
-                    used_boundary.add(x)
-        for k in fam_of_bin[k2]:
-            for r in (bins[k].re, bins[k].im):
-                if not r.zero and r.n in boundary:
-                    used_boundary.add(r.n)
-        emit("  {   // family k2 = %d: bins %s" % (k2, fam_of_bin[k2]))
-        for n in sorted(used_boundary):
-            kind, slot = boundary[n]
-            if kind == "ag":
-                emit("    const v2f t%d = v2f{unpark(ag[%d]), unpark(ag[%d])};" % (n, slot, slot + 1))
-            else:
-                emit("    const v2f t%d = sv[%d];" % (n, slot))
-        for n in nodes:
-            emit("  " + _fmt_node(g, n, OFF_FFT))
-        # X[k] = E + W^k O and |X[200-k]| = |E - W^k O| with W = exp(-2 pi i / 400); br/bi hold
-        # (E, O) in their two halves and cs = (cos, sin) of 2 pi k / 400.  Six packed
-        # instructions per bin, with operand-half selects and sign modifiers chosen by hand:
-        #   t  = (c O.re, s O.re)
-        #   T  = (s O.im + t.lo, c O.im - t.hi)            = W^k O
-        #   R  = (E.re + T.re, E.re - T.re),  I = (E.im + T.im, E.im - T.im)
-        #   M  = R R + I I                                 = (|X[k]|^2, |X[200-k]|^2)
-        # Two bins share one asm statement with their instructions interleaved: a packed result
-        # may not be consumed by the very next instruction, and the compiler does not pad
-        # hazards inside (or right after) an asm statement.
-        def neg(mask3):
-            return "[%s]" % ",".join(str(int(x)) for x in mask3)
-
-        def bin_instrs(tag, sr, si):
-            nr, ni = sr < 0, si < 0
-            return [
-                "v_pk_mul_f32 %%[t%s], %%[cs%s], %%[br%s] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:%s neg_hi:%s"
-                % (tag, tag, tag, neg((0, nr)), neg((0, nr))),
-                "v_pk_fma_f32 %%[t%s], %%[cs%s], %%[bi%s], %%[t%s] op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:%s neg_hi:%s"
-                % (tag, tag, tag, tag, neg((0, ni, 0)), neg((0, ni, 1))),
-                "v_pk_add_f32 %%[m%s], %%[br%s], %%[t%s] op_sel:[0,0] op_sel_hi:[0,0] neg_lo:%s neg_hi:%s"
-                % (tag, tag, tag, neg((nr, 0)), neg((nr, 1))),
-                "v_pk_add_f32 %%[i%s], %%[bi%s], %%[t%s] op_sel:[0,1] op_sel_hi:[0,1] neg_lo:%s neg_hi:%s"
-                % (tag, tag, tag, neg((ni, 0)), neg((ni, 1))),
-                "v_pk_mul_f32 %%[m%s], %%[m%s], %%[m%s]" % (tag, tag, tag),
-                "v_pk_fma_f32 %%[m%s], %%[i%s], %%[i%s], %%[m%s]" % (tag, tag, tag, tag),
-            ]
-
-        def val(r):
-            return "v2f{0.f, 0.f}" if r.zero else "t%d" % r.n
-
-        ks = fam_of_bin[k2]
-        for g0 in range(0, len(ks), 2):
-            grp = ks[g0:g0 + 2]
-            lines = ["s_nop 0"]      # the inputs may come straight from a packed instruction
-            seqs = [bin_instrs("ab"[i], 1 if bins[k].re.zero else bins[k].re.s,
-                               1 if bins[k].im.zero else bins[k].im.s) for i, k in enumerate(grp)]
-            if len(grp) == 2:
-                for x, y in zip(*seqs):
-                    lines += [x, y]
-                lines.append("s_nop 0")
-            else:
-                for x in seqs[0]:
-                    lines += [x, "s_nop 0"]
-            emit("    {")
-            outs, ins = [], []
-            for i, k in enumerate(grp):
-                tag = "ab"[i]
-                emit("      v2f m%s, t%s, i%s;" % (tag, tag, tag))
-                outs += ['[m%s] "=&v"(m%s)' % (tag, tag), '[t%s] "=&v"(t%s)' % (tag, tag),
-                         '[i%s] "=&v"(i%s)' % (tag, tag)]
-                ins += ['[cs%s] "s"(v2f{ct[OFF_TW + %d], ct[OFF_TW + %d]})' % (tag, 2 * k, 2 * k + 1),
-                        '[br%s] "v"(%s)' % (tag, val(bins[k].re)), '[bi%s] "v"(%s)' % (tag, val(bins[k].im))]
-            emit('      asm("%s"' % "\\n\\t".join(lines))
-            emit("          : %s" % ", ".join(outs))
-            emit("          : %s);" % ", ".join(ins))
-            for i, k in enumerate(grp):
-                tag = "ab"[i]
-                emit("      mag[%d] = park(m%s.x);" % (k, tag))
-                if k < 100:
-                    emit("      mag[%d] = park(m%s.y);" % (200 - k, tag))
-            emit("    }")
-        emit("  }")
-        emit("  __builtin_amdgcn_sched_barrier(0);")
-        emit("  slot(%d);" % k2)
-        if os.environ.get("LM_SLOT_BARRIER", "1") == "1":
-            emit("  __builtin_amdgcn_sched_barrier(0);")
-
-    n_fft_consts = len(g.consts)
-    off_fft = 0
-    off_win = off_fft + n_fft_consts           # 400 window values
-    off_tw = off_win + N_FFT                   # (cos, sin) of 2 pi k / 400, k = 0..100
-    off_mel80 = off_tw + 2 * 101
-    pairs80 = mel_structure(80)
-    off_mel128 = off_mel80 + len(pairs80)
-    pairs128 = mel_structure(128)
-    table_len = off_mel128 + len(pairs128)
-
-    out = []
-    emit = out.append
-    emit("// GENERATED by gen_logmel.py -- do not edit.")
-    emit("// real 200-point DFT on two interleaved sequences: %d live ops, %d constants"
-         % (sum(1 for n in live if g.nodes[n][0] != "in"), n_fft_consts))
-    emit("// self-check vs numpy rfft (float64 evaluation): max abs err %.3g" % err)
-    emit("")
-    emit("#define OFF_FFT %d" % off_fft)
-    emit("#define OFF_WIN %d" % off_win)
-    emit("#define OFF_TW %d" % off_tw)
-    emit("#define OFF_MEL80 %d" % off_mel80)
-    emit("#define OFF_MEL128 %d" % off_mel128)
-    emit("#define LOGMEL_TABLE_LEN %d" % table_len)
-    emit("#define LOGMEL_N_AG %d" % max(n_ag, 1))
-    emit("#define LOGMEL_N_SV %d" % max(n_sv, 1))
-    emit("")
-    emit("// Pass A.  base = this lane's frame start in LDS (rows of 164 floats).  Writes the")
-    emit("// eight 25-point sub-DFTs: parked in accumulator registers (ag) or kept (sv).")
-    emit("__device__ __forceinline__ void logmel_pass_a(const unsigned char* base, "
-         "lm_const_ptr ct, float (&ag)[LOGMEL_N_AG], v2f (&sv)[LOGMEL_N_SV]) {")
-    out.extend(body_a)
-    emit("}")
-    emit("")
-    emit("// Pass B: twiddles, 8-point DFTs, E/O combine; mag[k] = |X[k]|^2 (parked), k = 0..200.")
-    emit("// slot(k2) is called after family k2 (13 calls): the caller's hook for work to interleave.")
-    emit("template <class Slot>")
-    emit("__device__ __forceinline__ void logmel_pass_b(lm_const_ptr ct, "
-         "const float (&ag)[LOGMEL_N_AG], const v2f (&sv)[LOGMEL_N_SV], float (&mag)[201], "
-         "Slot&& slot) {")
-    out.extend(body_b)
-    emit("}")
-    emit("")
-    for n_mels, pairs, off in ((80, pairs80, "OFF_MEL80"), (128, pairs128, "OFF_MEL128")):
-        fb = mel_filterbank(16000, N_FFT, n_mels, 0.0, 8000.0)
-        emit("__device__ __forceinline__ void logmel_project_%d(const float (&mag)[201], "
-             "lm_const_ptr ct, float (&mel)[%d]) {" % (n_mels, n_mels))
-        i = 0
-        defined = set()
-        for m in range(n_mels):
-            terms = []
-            while i < len(pairs) and pairs[i][1] == m:
-                k = pairs[i][0]
-                if k not in defined:
-                    # the square root is taken after the value has left the accumulator file: an
-                    # asm statement must not read a transcendental result directly (the compiler
-                    # pads that hazard only for its own instructions)
-                    emit("  const float m%d = __builtin_amdgcn_sqrtf(unpark(mag[%d]));" % (k, k))
-                    defined.add(k)
-                if LITERALS & 4:
-                    terms.append("%s * m%d" % (_lit(fb[k, m]), k))
-                else:
-                    terms.append("ct[%s + %d] * m%d" % (off, i, k))
-                i += 1
-            emit("  mel[%d] = %s;" % (m, " + ".join(terms)))
-        emit("}")
-        emit("")
-    with open(os.path.join(HERE, "logmel_codelet.inc"), "w") as f:
-        f.write("\n".join(out))
-
-    # host-side table description
-    h = []
-    h.append("// GENERATED by gen_logmel.py -- do not edit.")
-    h.append("#pragma once")
-    h.append("#define LOGMEL_OFF_FFT %d" % off_fft)
-    h.append("#define LOGMEL_OFF_WIN %d" % off_win)
-    h.append("#define LOGMEL_OFF_TW %d" % off_tw)
-    h.append("#define LOGMEL_OFF_MEL80 %d" % off_mel80)
-    h.append("#define LOGMEL_OFF_MEL128 %d" % off_mel128)
-    h.append("#define LOGMEL_TABLE_LEN %d" % table_len)
-    h.append("#define LOGMEL_N_FFT_CONSTS %d" % n_fft_consts)
-    h.append("static const float logmel_fft_consts[%d] = {" % n_fft_consts)
-    h.append(",\n".join("  %.9ef" % v for v in g.consts))
-    h.append("};")
-    for n_mels, pairs in ((80, pairs80), (128, pairs128)):
-        h.append("#define LOGMEL_NNZ_%d %d" % (n_mels, len(pairs)))
-        h.append("// (bin, filter) of every weight slot, in table order")
-        h.append("static const unsigned short logmel_nz_%d[%d][2] = {" % (n_mels, len(pairs)))
-        h.append(",\n".join("  {%d, %d}" % p for p in pairs))
-        h.append("};")
-    with open(os.path.join(HERE, "logmel_tables.h"), "w") as f:
-        f.write("\n".join(h) + "\n")
-    print("fft ops: %d  consts: %d  table floats: %d  ag %d  sv %d  self-check err %.3g"
-          % (sum(1 for n in live if g.nodes[n][0] != "in"), n_fft_consts, table_len, n_ag, n_sv, err))
+            src0 = next((r for r in free[0] if r not in [m[1] for m in moves]), None)
+            copy_s = False
+        vname, sname = "mg[%s]" % vdst, "mg[%s]" % src0
+        if vdst is None:            # nothing free to receive in: a scratch register of its own
+            vname = "xt[%d]" % n_tmp
+            n_tmp += 1
+        if src0 is None:
+            sname = "xt[%d]" % n_tmp
+            n_tmp += 1
+        if copy_v:
+            vname = "xt[%d]" % n_tmp
+            n_tmp += 1
+        if copy_s:
+            sname = "xt[%d]" % n_tmp
+            n_tmp += 1
+        # a register may take part in one move only (its content changes)
+        if not copy_v and vdst is not None:
+            if vdst in free[1]:
+                free[1].remove(vdst)
+        if not copy_s and src0 is not None:
+            if src0 in free[0]:
+                free[0].remove(src0)
+        moves.append((vdst, src0, vname if (copy_v or vdst is None) else None, sname if (copy_s or src0 is None) else None))
+        if a is not None:
+            loc[0][a] = sname                                 # lower finds bin a where it sent from
+        if b is not None:
+            loc[1][b] = vname
+    # sanity: a register that receives must not be needed (under its own name) by the receiver
+    for vdst, src0, cv, cs in moves:
+        if cs is None:
+            assert src0 not in used[0], "lower register %d overwritten while needed" % src0
+        if cv is None:
+            assert vdst not in used[1], "upper register %d overwritten while needed" % vdst
+    assert len({m[0] for m in moves if m[2] is None}) == len([m for m in moves if m[2] is None])
+    assert len({m[1] for m in moves if m[3] is None}) == len([m for m in moves if m[3] is None])
+    return moves, loc, pairs, n_tmp
 
 
-def _lit(v):
-    return "%.9ef" % float(np.float32(v))
+def lds_off(nn):
+    return (nn // 160) * (164 * 4) + (nn % 160) * 4
 
 
-def _fmt_node(g, n, off_fft):
+def fmt_node(g, n):
     op, a, b, c = g.nodes[n]
-    if op == "mul" and LITERALS & 1:
-        return "  const v2f t%d = t%d * %s;" % (n, a, _lit(g.consts[c]))
     if op == "add":
         return "  const v2f t%d = t%d + t%d;" % (n, a, b)
     if op == "sub":
@@ -658,10 +411,391 @@ def _fmt_node(g, n, off_fft):
     raise ValueError(op)
 
 
-N_SUBS_IN_AGPR = 5
-HANN = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(400) / 400)).astype(np.float32)   # periodic Hann
-LITERALS = int(os.environ.get("LOGMEL_LITERALS", "0"))   # 1 fft constants, 2 twiddles, 4 mel weights
-PASS_A_ORDER = [(0,), (2,), (4,), 6, 7]     # (j,) = the pair j, j+1 from one 16-byte load
+def rexpr(r):
+    if r.zero:
+        return "v2f{0.f, 0.f}"
+    return ("-" if r.s < 0 else "") + "t%d" % r.n
+
+
+# --------------------------------------------------------------------------
+# numpy emulation of the lane pair (checks the plan and the tables)
+# --------------------------------------------------------------------------
+def emulate(x, n_mels, hann, fb):
+    """x: [400] float64 frame -> mel [n_mels] by the lane-pair dataflow."""
+    g, bins, _ = build_fft()
+    roots = []
+    for b in bins:
+        roots += [b.re.n, b.im.n]
+    live = live_nodes(g, [r for r in roots if r is not None])
+    xw = x * hann
+    s = xw[0::2] + 1j * 0          # packed halves handled as two real sequences
+    e, o = xw[0::2], xw[1::2]
+    S = []
+    for p in (0, 1):
+        out = []
+        for seq in (e, o):
+            val = evaluate(g, live, seq[p::2])
+            def get(r):
+                return 0.0 if r.zero else r.s * val[r.n]
+            out.append(np.array([complex(get(b.re), get(b.im)) for b in bins]))
+        S.append(out)              # S[p][half e/o][k]
+    mg = [np.zeros(104), np.zeros(104)]
+    for i, (_, kl, ku) in enumerate(kappa_slots()):
+        for h, kap in ((0, kl), (1, ku)):
+            if kap is None:
+                continue
+            tw = twiddles(kap)
+            w200 = complex(tw[0][0], -tw[0][1])
+            U, V = [], []
+            for half in (0, 1):
+                T = w200 * S[1][half][kap]
+                U.append(S[0][half][kap] + T)
+                V.append(S[0][half][kap] - T)
+            wu = complex(tw[1][0], -tw[1][1])
+            wv = complex(tw[2][0], -tw[2][1])
+            mg[h][4 * i + 0] = abs(U[0] + wu * U[1])
+            mg[h][4 * i + 1] = abs(U[0] - wu * U[1])
+            mg[h][4 * i + 2] = abs(V[0] + wv * V[1])
+            mg[h][4 * i + 3] = abs(V[0] - wv * V[1])
+    moves, loc, pairs, n_tmp = exchange_plan(n_mels)
+    xt = [np.zeros(max(n_tmp, 1)), np.zeros(max(n_tmp, 1))]
+    regs = [{"mg": mg[0], "xt": xt[0]}, {"mg": mg[1], "xt": xt[1]}]
+
+    def ref(h, name):
+        arr, idx = name[:2], int(name[3:-1])
+        return regs[h][arr], idx
+    for vdst, src0, cv, cs in moves:
+        vname, sname = cv or "mg[%d]" % vdst, cs or "mg[%d]" % src0
+        for h in (0, 1):
+            if cv and vdst is not None:
+                a, i = ref(h, cv); a[i] = regs[h]["mg"][vdst]
+            if cs and src0 is not None:
+                a, i = ref(h, cs); a[i] = regs[h]["mg"][src0]
+        au, iu = ref(1, vname)
+        al, il = ref(0, sname)
+        au[iu], al[il] = al[il], au[iu]
+    mel = np.zeros(n_mels)
+    for h in (0, 1):
+        for k, m in pairs[h]:
+            a, i = ref(h, loc[h][k])
+            mel[m] += fb[k, m] * a[i]
+    return mel
+
+
+def self_check():
+    hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(400) / 400)
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for n_mels in (80, 128):
+        fb = mel_filterbank(16000, N_FFT, n_mels, 0.0, 8000.0).astype(np.float64)
+        for _ in range(3):
+            x = rng.standard_normal(400)
+            want = np.abs(np.fft.rfft(x * hann)) @ fb
+            got = emulate(x, n_mels, hann, fb)
+            worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+    assert worst < 1e-6, "lane-pair dataflow disagrees with numpy: %g" % worst
+    return worst
+
+
+# --------------------------------------------------------------------------
+# emit
+# --------------------------------------------------------------------------
+def main():
+    err = self_check()
+    g, bins, subs = build_fft()
+    roots = []
+    for b in bins:
+        roots += [b.re.n, b.im.n]
+    live = live_nodes(g, [r for r in roots if r is not None])
+
+    # ---- pass A: four 25-point real sub-DFTs
+    boundary, sub_nodes, n_sa = {}, [], 0
+    for j in range(4):
+        rts = []
+        for b in subs[j]:
+            rts += [b.re.n, b.im.n]
+        rts = [r for r in rts if r is not None]
+        nodes = sorted(live_nodes(g, rts) & live)
+        sub_nodes.append(nodes)
+        for n in sorted(set(rts) & live):
+            if n not in boundary:
+                boundary[n] = n_sa
+                n_sa += 1
+    pass_a_nodes = set(n for nodes in sub_nodes for n in nodes)
+
+    body_a = []
+    emit = body_a.append
+    win_pos = []                 # [j][position in consumption order] -> m2
+    for j in range(4):
+        emit("  // sub-DFT %d: packed inputs s[2 (j + 4 m2) + p] = frame samples 4 (j + 4 m2) + 2 p, +1;" % j)
+        emit("  // every input and its window pair are fetched right before the first use")
+        # consumption order of the inputs
+        order = []
+        for n in sub_nodes[j]:
+            op, a, b, c = g.nodes[n]
+            if op == "in":
+                continue
+            for x in (a, b):
+                if x is not None and g.nodes[x][0] == "in" and x not in order:
+                    order.append(x)
+        for n in sub_nodes[j]:           # inputs that are outputs themselves (none expected)
+            if g.nodes[n][0] == "in" and n not in order:
+                order.append(n)
+        assert len(order) == 25
+        win_pos.append([(g.nodes[n][1] - j) // 4 for n in order])
+        loaded_w, done_in = set(), set()
+
+        def need_input(n):
+            if n in done_in:
+                return
+            done_in.add(n)
+            pos = order.index(n)
+            m2 = (g.nodes[n][1] - j) // 4
+            emit("  const v2f q%d_%d = *(const v2f*)(base + %d);" % (j, m2, lds_off(4 * (j + 4 * m2))))
+            wi = pos // 2
+            if wi not in loaded_w:
+                loaded_w.add(wi)
+                if wi < 12:
+                    emit("  const v4f w%d_%d = *(const v4f*)(wt + %d);" % (j, wi, (26 * j + 2 * wi) * 8))
+                else:
+                    emit("  const v2f w%d_%d = *(const v2f*)(wt + %d);" % (j, wi, (26 * j + 2 * wi) * 8))
+            if wi == 12:
+                w = "w%d_12" % j
+            elif pos % 2 == 0:
+                w = "v2f{w%d_%d.x, w%d_%d.y}" % (j, wi, j, wi)
+            else:
+                w = "v2f{w%d_%d.z, w%d_%d.w}" % (j, wi, j, wi)
+            emit("  const v2f t%d = q%d_%d * %s;" % (n, j, m2, w))
+
+        for n in sub_nodes[j]:
+            op, a, b, c = g.nodes[n]
+            if op == "in":
+                continue
+            for x in (a, b):
+                if x is not None and g.nodes[x][0] == "in":
+                    need_input(x)
+            emit(fmt_node(g, n))
+        for n in order:
+            need_input(n)
+        for n in sub_nodes[j]:
+            if n in boundary:
+                emit("  sa[%d] = t%d;" % (boundary[n], n))
+        # pin the results here: pure arithmetic would otherwise be sunk past the workgroup barrier
+        # to its first use, where all four sub-DFTs would then be live at once
+        for n in sub_nodes[j]:
+            if n in boundary:
+                emit("  asm volatile(\"\" : \"+v\"(sa[%d]));" % boundary[n])
+        emit("  __builtin_amdgcn_sched_barrier(0);")
+
+    # ---- pass B + combine, family by family
+    body_b = []
+    emit = body_b.append
+    emitted = set(pass_a_nodes)
+    slots = kappa_slots()
+    for f in range(13):
+        ks = sorted({k for k in range(51) if k % 25 in (f, 25 - f)})
+        rts = []
+        for k in ks:
+            rts += [bins[k].re.n, bins[k].im.n]
+        rts = [r for r in rts if r is not None]
+        nodes = sorted((live_nodes(g, rts) & live) - emitted)
+        emitted |= set(nodes)
+        used_boundary = set()
+        for n in nodes:
+            op, a, b, c = g.nodes[n]
+            for x in (a, b):
+                if x is not None and x in boundary:
+                    used_boundary.add(x)
+        for k in ks:
+            for r in (bins[k].re, bins[k].im):
+                if not r.zero and r.n in boundary:
+                    used_boundary.add(r.n)
+        emit("  {   // family %d: S_p[k] for k in %s" % (f, ks))
+        for n in sorted(used_boundary):
+            emit("    const v2f t%d = sa[%d];" % (n, boundary[n]))
+        for n in nodes:
+            emit("  " + fmt_node(g, n))
+        mine = [(i, kl, ku) for i, (ff, kl, ku) in enumerate(slots) if ff == f]
+        for j, (i, kl, ku) in enumerate(mine):
+            # registers a (vdst) = S_p[kl], b (src0) = S_p[ku]; after the swap a = S_0[kappa], b = S_1[kappa]
+            kb = ku if ku is not None else kl
+            # kappa 25 pairs with itself: the partner's value arrives in a copy
+            for comp, ra, rb in (("r", bins[kl].re, bins[kb].re), ("i", bins[kl].im, bins[kb].im)):
+                for h in ("x", "y"):
+                    emit("    float a%s%s%d = (%s).%s, b%s%s%d = (%s).%s;"
+                         % (comp, h, i, rexpr(ra), h, comp, h, i, rexpr(rb), h))
+            emit("    lm_swap4(arx%d, brx%d, ary%d, bry%d, aix%d, bix%d, aiy%d, biy%d);" % ((i,) * 8))
+            emit("    const v2f ar%d = v2f{arx%d, ary%d}, ai%d = v2f{aix%d, aiy%d};" % (i, i, i, i, i, i))
+            emit("    const v2f br%d = v2f{brx%d, bry%d}, bi%d = v2f{bix%d, biy%d};" % (i, i, i, i, i, i))
+            # this kappa's three twiddle pairs: 24 bytes at tt + 48 f + 24 j
+            o = f * 48 + 24 * j
+            emit("    const v2f w%d = *(const v2f*)(tt + %d), cu%d = *(const v2f*)(tt + %d), cv%d = *(const v2f*)(tt + %d);"
+                 % (i, o, i, o + 8, i, o + 16))
+            emit("    const v2f Tr%d = br%d * w%d.x + bi%d * w%d.y, Ti%d = bi%d * w%d.x - br%d * w%d.y;"
+                 % (i, i, i, i, i, i, i, i, i, i))
+            emit("    const v2f Ur%d = ar%d + Tr%d, Ui%d = ai%d + Ti%d, Vr%d = ar%d - Tr%d, Vi%d = ai%d - Ti%d;"
+                 % (i, i, i, i, i, i, i, i, i, i, i, i))
+            emit("    v2f mu%d, mv%d;" % (i, i))
+            emit("    lm_combine2(cu%d, Ur%d, Ui%d, mu%d, cv%d, Vr%d, Vi%d, mv%d);" % (i, i, i, i, i, i, i, i))
+            emit("    mg[%d] = __builtin_amdgcn_sqrtf(mu%d.x); mg[%d] = __builtin_amdgcn_sqrtf(mu%d.y);"
+                 % (4 * i, i, 4 * i + 1, i))
+            emit("    mg[%d] = __builtin_amdgcn_sqrtf(mv%d.x); mg[%d] = __builtin_amdgcn_sqrtf(mv%d.y);"
+                 % (4 * i + 2, i, 4 * i + 3, i))
+            if j == 0:
+                emit("    __builtin_amdgcn_sched_barrier(0);")
+        emit("  }")
+        emit("  __builtin_amdgcn_sched_barrier(0);")
+        emit("  slot(%d);" % f)
+        emit("  __builtin_amdgcn_sched_barrier(0);")
+
+    # ---- tables
+    n_fft_consts = len(g.consts)
+    off_fft = 0
+    off_mel = {}
+    cursor = off_fft + n_fft_consts
+    plans = {}
+    for n_mels in (80, 128):
+        plans[n_mels] = exchange_plan(n_mels)
+        off_mel[n_mels] = cursor
+        cursor += len(plans[n_mels][2][0]) + len(plans[n_mels][2][1])
+    table_len = cursor
+
+    out = []
+    emit = out.append
+    emit("// GENERATED by gen_logmel.py -- do not edit.")
+    emit("// real 100-point DFT per lane on packed (even, odd) pairs: %d live ops, %d constants"
+         % (sum(1 for n in live if g.nodes[n][0] != "in"), n_fft_consts))
+    emit("// lane-pair dataflow checked against numpy (float64): max rel err %.3g" % err)
+    emit("")
+    emit("#define OFF_FFT %d" % off_fft)
+    emit("#define OFF_MEL80 %d" % off_mel[80])
+    emit("#define OFF_MEL128 %d" % off_mel[128])
+    emit("#define LOGMEL_TABLE_LEN %d" % table_len)
+    emit("#define LOGMEL_N_SA %d" % n_sa)
+    emit("#define LOGMEL_WIN_BYTES 1664      // [half][sub-DFT j][26] pairs (w[4m+2p], w[4m+2p+1]), m = j + 4 m2 (m2 = 25 is padding)")
+    emit("#define LOGMEL_TW_BYTES 1248       // [half][family][6] (cos, sin)")
+    emit("")
+    emit("// Pass A.  base = LDS address of this lane's frame start + 8 * half; wt = LDS address of the")
+    emit("// half's window table.  Writes the four 25-point sub-DFTs to sa.")
+    emit("__device__ __forceinline__ void logmel_pass_a(const unsigned char* base, const unsigned char* wt,")
+    emit("                                               lm_const_ptr ct, v2f (&sa)[LOGMEL_N_SA]) {")
+    out.extend(body_a)
+    emit("}")
+    emit("")
+    emit("// Pass B, the lane-pair exchange and both combines: mg[4 i + c] = |X[b]| for the c-th bin of")
+    emit("// this half's i-th kappa (see kappa_slots in the generator).  tt = LDS address of the half's")
+    emit("// twiddle table.  slot(f) is called after family f (13 calls).")
+    emit("template <class Slot>")
+    emit("__device__ __forceinline__ void logmel_pass_b(lm_const_ptr ct, const unsigned char* tt,")
+    emit("                                               const v2f (&sa)[LOGMEL_N_SA], float (&mg)[104], Slot&& slot) {")
+    out.extend(body_b)
+    emit("}")
+    emit("")
+    for n_mels in (80, 128):
+        moves, loc, pairs, n_tmp = plans[n_mels]
+        split = SPLIT[n_mels]
+        na = max(split, n_mels - split)
+        emit("#define LOGMEL_SPLIT_%d %d" % (n_mels, split))
+        emit("#define LOGMEL_NACC_%d %d" % (n_mels, na))
+        emit("// acc[i] = filter i (lower half) / filter %d + i (upper half; entries past %d repeat acc[0])"
+             % (split, n_mels - split))
+        emit("__device__ __forceinline__ void logmel_project_%d(float (&mg)[104], lm_const_ptr ct, bool upper, "
+             "float (&acc)[%d]) {" % (n_mels, na))
+        emit("  float xt[%d];" % max(n_tmp, 1))
+        for vdst, src0, cv, cs in moves:
+            if cv:
+                emit("  %s = %s;" % (cv, "mg[%d]" % vdst if vdst is not None else "0.f"))
+            if cs:
+                emit("  %s = %s;" % (cs, "mg[%d]" % src0 if src0 is not None else "0.f"))
+        names = [(cv or "mg[%d]" % vdst, cs or "mg[%d]" % src0) for vdst, src0, cv, cs in moves]
+        # four swaps per asm statement; a register may appear only once in a statement (each operand
+        # of an asm statement is read before and written after it, independently of the others)
+        while names:
+            grp, rest, seen = [], [], set()
+            for n in names:
+                if len(grp) < 4 and n[0] not in seen and n[1] not in seen and n[0] != n[1]:
+                    grp.append(n)
+                    seen.update(n)
+                else:
+                    rest.append(n)
+            # order must be kept between moves that share a register: only take a prefix-safe group
+            safe = []
+            blocked = set()
+            for n in names:
+                if n in grp and n[0] not in blocked and n[1] not in blocked:
+                    safe.append(n)
+                else:
+                    blocked.update(n)
+            grp = safe
+            names = [n for n in names if n not in grp]
+            if len(grp) == 4:
+                emit("  lm_swap4(%s);" % ", ".join("%s, %s" % n for n in grp))
+            else:
+                for n in grp:
+                    emit("  lm_swap(%s, %s);" % n)
+        off = "OFF_MEL%d" % n_mels
+        pos = 0
+        for h in (0, 1):
+            emit("  if (%supper) {" % ("" if h else "!"))
+            i = 0
+            ps = pairs[h]
+            first = 0 if h == 0 else split
+            count = split if h == 0 else n_mels - split
+            for m in range(first, first + count):
+                terms = []
+                while i < len(ps) and ps[i][1] == m:
+                    terms.append("ct[%s + %d] * %s" % (off, pos, loc[h][ps[i][0]]))
+                    i += 1
+                    pos += 1
+                emit("    acc[%d] = %s;" % (m - first, " + ".join(terms)))
+            for m in range(count, na):
+                emit("    acc[%d] = acc[0];" % m)
+            emit("  }")
+        emit("}")
+        emit("")
+    with open(os.path.join(HERE, "logmel_codelet.inc"), "w") as f:
+        f.write("\n".join(out))
+
+    # ---- host-side description
+    h = []
+    h.append("// GENERATED by gen_logmel.py -- do not edit.")
+    h.append("#pragma once")
+    h.append("#define LOGMEL_OFF_FFT %d" % off_fft)
+    h.append("#define LOGMEL_OFF_MEL80 %d" % off_mel[80])
+    h.append("#define LOGMEL_OFF_MEL128 %d" % off_mel[128])
+    h.append("#define LOGMEL_TABLE_LEN %d" % table_len)
+    h.append("#define LOGMEL_N_FFT_CONSTS %d" % n_fft_consts)
+    h.append("static const float logmel_fft_consts[%d] = {" % n_fft_consts)
+    h.append(",\n".join("  %.9ef" % v for v in g.consts))
+    h.append("};")
+    # twiddle table [half][family][6][2], as doubles' nearest floats
+    tw = np.zeros((2, 13, 6, 2), np.float64)
+    for f in range(13):
+        mine = [(kl, ku) for ff, kl, ku in slots if ff == f]
+        for j, (kl, ku) in enumerate(mine):
+            for hh, kap in ((0, kl), (1, ku if ku is not None else kl)):
+                for p, (c, s) in enumerate(twiddles(kap)):
+                    tw[hh, f, 3 * j + p] = (c, s)
+    h.append("// window pair at position i of sub-DFT j's LDS table belongs to input m2 = logmel_win_pos[j][i]")
+    h.append("static const unsigned char logmel_win_pos[4][25] = {")
+    h.append(",\n".join("  {%s}" % ", ".join(str(v) for v in row) for row in win_pos))
+    h.append("};")
+    h.append("static const float logmel_twiddles[%d] = {" % tw.size)
+    h.append(",\n".join("  %.9ef" % v for v in tw.reshape(-1)))
+    h.append("};")
+    for n_mels in (80, 128):
+        pairs = plans[n_mels][2]
+        allp = pairs[0] + pairs[1]
+        h.append("#define LOGMEL_NNZ_%d %d" % (n_mels, len(allp)))
+        h.append("// (bin, filter) of every weight slot, in table order")
+        h.append("static const unsigned short logmel_nz_%d[%d][2] = {" % (n_mels, len(allp)))
+        h.append(",\n".join("  {%d, %d}" % p for p in allp))
+        h.append("};")
+    with open(os.path.join(HERE, "logmel_tables.h"), "w") as f:
+        f.write("\n".join(h) + "\n")
+    print("fft ops: %d  consts: %d  table floats: %d  sa %d  swaps %d/%d (tmp %d/%d)  self-check err %.3g"
+          % (sum(1 for n in live if g.nodes[n][0] != "in"), n_fft_consts, table_len, n_sa,
+             len(plans[80][0]), len(plans[128][0]), plans[80][3], plans[128][3], err))
 
 
 if __name__ == "__main__":

@@ -7,16 +7,15 @@
 //                                mel projection, log10 / clamp, global max-8,
 //                                (x+4)/4)
 // with two kernels:
-//   logmel_main      one lane = one frame.  A 256-lane workgroup owns a tile of
-//                    247 consecutive frames whose PCM span is brought into LDS
-//                    once (LDS-DMA, each sample leaves HBM once apart from a
-//                    240-sample halo per tile), the next tile's span is fetched
-//                    while the current one is transformed in registers (real
-//                    200-point DFT pair, see gen_logmel.py), and every lane
-//                    writes its own output row.  It stores z = (log10(mel)+4)/4,
-//                    the clip maximum of log10(mel) (float atomic max) and, per
-//                    wave, the minimum z.
-//   logmel_finalize  applies max(z, ((gmax-8)+4)/4) only to the 64-row segments
+//   logmel_pair      two lanes = one frame (lane l and lane l + 32 of a wave).  A
+//                    256-lane workgroup owns a tile of 118 consecutive frames whose
+//                    PCM span is brought into LDS once (LDS-DMA, each sample leaves
+//                    HBM once apart from a 240-sample halo per tile), the next
+//                    tile's span is fetched while the current one is transformed in
+//                    registers (gen_logmel.py), and every lane writes its part of
+//                    its frame's output row.  It stores z = (log10(mel)+4)/4, the
+//                    clip maximum of log10(mel) and, per wave, the minimum z.
+//   logmel_finalize  applies max(z, ((gmax-8)+4)/4) only to the 32-row segments
 //                    whose recorded minimum is below the threshold.  x -> (x+4)/4
 //                    is monotone in float arithmetic, so clamping after the
 //                    scaling gives bit-identical results to clamping before it.
@@ -27,31 +26,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const float __attribute__((address_space(4)))* lm_const_ptr;   // scalar-load (constant) view of the table
 
-// Park a value in / fetch it from the accumulator half of the register file.  With one
-// wave per SIMD a lane owns 256 VGPRs + 256 AGPRs; the 400 floats that live between the two
-// DFT passes do not fit in the VGPR half alone.
-__device__ __forceinline__ float park(float v) {
-  float a;
-  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
-  return a;
-}
-__device__ __forceinline__ float unpark(float a) {
-  float v;
-  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-  return v;
-}
-
-#include "logmel_codelet.inc"
-
 #define LM_HOP 160
 #define LM_NFFT 400
-#define LM_TILE_FRAMES 247                 // frames per workgroup tile
-#define LM_ROWS (LM_TILE_FRAMES + 2)       // 160-sample rows held in LDS
-#define LM_PITCH 164                       // floats per LDS row (160 + 4 pad: 16-B aligned,
-                                           // conflict-free ds_read_b128 across lanes)
+#define LM_PITCH 164                       // floats per LDS row (160 + 4 pad: rows stay 16-byte aligned)
 #define LM_CHUNKS_PER_ROW 41               // 16-byte pieces per row (40 data + 1 pad)
-#define LM_LDS_BYTES 163840                // whole LDS: 160 DMA instructions x 1 KiB
-#define LM_DMA_PER_WAVE 40
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -67,39 +45,6 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-// Issue instructions [i0, i1) of this wave's share (LM_DMA_PER_WAVE in all) of the LDS-DMA
-// that brings one tile's PCM span in.  LDS piece q (16 B) = row q / 41, piece q % 41 of that
-// row; the pad piece of a row re-reads the row's last data piece.  g0r = index, relative to
-// pcm[0], of the tile's first sample (may be negative); source indices are clamped into
-// [0, hi_r - 4] (hi_r a multiple of 4, so every piece is a 16-byte aligned load); what lies
-// outside is repaired by patch_reflect().
-__device__ __forceinline__ void issue_tile_dma(const float* __restrict__ pcm, int g0r, int hi_r,
-                                               unsigned char* lds, int wave, int lane, int i0,
-                                               int i1) {
-#pragma unroll 4
-  for (int i = i0; i < i1; ++i) {
-    const int inst = wave + 4 * i;
-    const int q = inst * 64 + lane;
-    const int r = q / LM_CHUNKS_PER_ROW;
-    int cc = q - r * LM_CHUNKS_PER_ROW;
-    cc = cc > 39 ? 39 : cc;
-    int s = g0r + r * LM_HOP + 4 * cc;
-    s = s > hi_r - 4 ? hi_r - 4 : s;
-    s = s < 0 ? 0 : s;
-    // uniform base + 32-bit lane offset: one address register per instruction
-    __builtin_amdgcn_global_load_lds((glb_void*)((const char*)pcm + (unsigned)(s * 4)),
-                                     (lds_void*)(lds + inst * 1024), 16, 0, 0);
-  }
-}
-
-// The same transfer for a tile whose span, plus one row of slack, lies inside [0, hi_r): one
-// instruction per LDS row, rows wave, wave + 4, ...  An instruction covers 1024 LDS bytes, a
-// row 656, so lanes 41..63 land on pieces 0..22 of the following row and fetch exactly the
-// samples that belong there (lane 40 fills the pad piece); whichever instruction writes a
-// byte last writes the same value.  Source and destination are uniform per instruction, so
-// issuing costs scalar work only, which is what lets the main loop drip the transfer in
-// between its register-starved compute sections.  The last instalments clamp to the last row.
-#define LM_ROW_DMA_PER_WAVE ((LM_ROWS + 3) / 4)
 #ifndef LM_DMA_PARTS
 #define LM_DMA_PARTS 4
 #endif
@@ -108,16 +53,6 @@ struct RowDma {
   unsigned lds0;        // uniform: LDS byte address of row `wave`
   unsigned lane_off;    // per lane: source byte offset inside the instruction
 };
-__device__ __forceinline__ void issue_rows_dma(const RowDma& d, int wave, int i0, int i1) {
-#pragma unroll
-  for (int i = i0; i < i1; ++i) {
-    int di = 4 * i;                              // rows past this wave's first
-    if (4 * i + 3 >= LM_ROWS) di = min(di, LM_ROWS - 1 - wave);
-    __builtin_amdgcn_global_load_lds((glb_void*)(d.base + (long)di * (LM_HOP * 4) + d.lane_off),
-                                     (lds_void*)(size_t)(d.lds0 + di * (LM_PITCH * 4)), 16, 0, 0);
-  }
-}
-
 // s_waitcnt immediates (vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 #define LM_WAIT_VM0 0x0F70      // vector memory (incl. LDS-DMA) drained
 #define LM_WAIT_LGKM0 0xC07F    // LDS / scalar loads drained
@@ -130,43 +65,6 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// Reflect padding (np.pad mode='reflect', stft.py:251-255): the samples before
-// the clip start and after its end, as far as a valid frame can reach.
-__device__ __forceinline__ void patch_reflect(const float* __restrict__ pcm, long origin,
-                                              long n_total, long hi_al, long g0, float* lds,
-                                              int tid) {
-  if (tid < 200) {
-    {   // g in [-200, 0)  ->  x[-g]
-      const long g = -200 + tid;
-      const long i = g - g0;
-      if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
-        const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
-        lds[r * LM_PITCH + c] = pcm[-g - origin];
-      }
-    }
-  }
-  if (tid < 204) {   // g in [hi_al, hi_al + 204): the unaligned clip tail, then x[2(N-1) - g]
-    const long g = hi_al + tid;
-    const long i = g - g0;
-    if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
-      const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
-      long src = g < n_total ? g : 2 * (n_total - 1) - g;
-      src = src < origin ? origin : src;      // only reached by rows no valid frame reads
-      lds[r * LM_PITCH + c] = pcm[src - origin];
-    }
-  }
-}
-
-template <int NMELS>
-__device__ __forceinline__ void project(const float (&mag)[201], lm_const_ptr ct,
-                                        float (&mel)[NMELS]);
-template <>
-__device__ __forceinline__ void project<80>(const float (&mag)[201], lm_const_ptr ct,
-                                            float (&mel)[80]) { logmel_project_80(mag, ct, mel); }
-template <>
-__device__ __forceinline__ void project<128>(const float (&mag)[201], lm_const_ptr ct,
-                                             float (&mel)[128]) { logmel_project_128(mag, ct, mel); }
-
 struct LogmelArgs {
   const float* pcm;      // pcm[0] = sample `origin` of the clip
   long origin;           // clip index of pcm[0]
@@ -175,239 +73,24 @@ struct LogmelArgs {
   long frame_begin;      // first frame of this piece
   long frame_count;      // frames in this piece
   int n_tiles;
-  const float* ct;       // constant table, LOGMEL_TABLE_LEN floats
+  const float* ct;       // constant table (scalar loads): DFT constants, mel weights
+  const float* lds_table;  // window and twiddle tables, copied into LDS by every workgroup
   float* out;            // [frame_count][NMELS], row 0 = frame_begin
   float* piece_max;      // written by the block that finishes last
   float* seg_min;        // [n_tiles * 4]
   unsigned* ticket;      // plan-owned, zero between launches
   float* blk_max;        // plan-owned, one slot per block
-  const float* lds_table;  // two-lanes-per-frame kernel: window and twiddle tables copied into LDS
-  float* dbg;              // development aid: per-lane dump of the first tile (null in normal use)
+  float* dbg;            // development builds (LM_DEBUG): per-lane dump of the first tile
 };
-
-// BULK: the piece is long enough (host-checked: hi_al - origin >= (LM_ROWS + 1) * 160) for the
-// branch-free row transfer.  It always reads a span that lies inside the piece: for a tile at
-// either end of the piece the span is shifted inward, the rows it brings are wrong, and the
-// tile is fetched again, clamped lane by lane, when its turn comes (two tiles per piece).
-template <int NMELS, bool BULK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void logmel_main(const LogmelArgs a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM_LDS_BYTES];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // the table is read through the constant address space so every access is a scalar load
-  // (a plain global pointer is demoted to per-lane vector loads once the loop also stores)
-  const lm_const_ptr ct = (lm_const_ptr)(unsigned long long)a.ct;
-
-  int tile = blockIdx.x;
-  if (tile >= a.n_tiles) return;
-  const int hi_r = (int)(a.hi_al - a.origin);
-  issue_tile_dma(a.pcm, (int)((a.frame_begin + (long)tile * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin),
-                 hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
-  __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
-
-#ifdef LM_TIMING
-  unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned tlast = (unsigned)__builtin_amdgcn_s_memtime();
-#define LM_TICK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define LM_TICK(i)
-#endif
-  float run_max = -__builtin_inff();
-  while (tile < a.n_tiles) {
-    const long t0 = a.frame_begin + (long)tile * LM_TILE_FRAMES;
-    const long g0 = t0 * LM_HOP - 200;
-    block_barrier();                        // every wave's DMA pieces of this tile have landed
-    LM_TICK(0)
-    if (g0 < 0 || g0 + (long)(LM_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
-      if (BULK) {
-        issue_tile_dma(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
-        __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
-        block_barrier();
-      }
-      patch_reflect(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
-      __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
-      block_barrier();
-    }
-
-    // pass A straight from LDS: sample n of this lane's frame sits at row tid + n/160, col n%160
-    float ag[LOGMEL_N_AG];
-    v2f sv[LOGMEL_N_SV];
-    LM_TICK(1)
-    logmel_pass_a(lds + tid * (LM_PITCH * 4), ct, ag, sv);
-    __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
-    LM_TICK(2)
-    block_barrier();                        // LDS may now be refilled
-    LM_TICK(3)
-    const int next = tile + gridDim.x;
-    int g0r_next = (int)((a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin);
-    if (!BULK && next < a.n_tiles)
-      issue_tile_dma(a.pcm, g0r_next, hi_r, lds, wave, lane, 0, LM_DMA_PER_WAVE);
-    // BULK: the next tile's rows are requested in LM_DMA_PARTS instalments between the families
-    // of pass B, so the wave never sits behind a full memory queue.  An instalment is straight
-    // scalar code rebuilt from scratch each time: nothing extra stays live across the
-    // register-starved compute sections and pass B remains a single basic block.  (Past the
-    // last tile it fetches a span nobody reads.)
-    g0r_next = min(max(g0r_next, 0), hi_r - (LM_ROWS + 1) * LM_HOP);
-    float mag[201];
-    logmel_pass_b(ct, ag, sv, mag, [&](int k2) __attribute__((always_inline)) {
-      constexpr int kEvery = 13 / LM_DMA_PARTS;
-      if (BULK && k2 % kEvery == 0 && k2 / kEvery < LM_DMA_PARTS) {
-        const int part = k2 / kEvery;
-        RowDma rd;
-        rd.base = (const char*)a.pcm + ((long)g0r_next + wave * LM_HOP) * 4;
-        rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * (LM_PITCH * 4);
-        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
-        rd.lane_off = ln * 16 - (ln >= 40 ? 16 : 0);
-        issue_rows_dma(rd, wave, (LM_ROW_DMA_PER_WAVE * part) / LM_DMA_PARTS,
-                       (LM_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
-      }
-    });
-#ifdef LM_TIMING
-    asm volatile("" :: "a"(mag[0]), "a"(mag[100]), "a"(mag[200]), "a"(mag[37]));
-#endif
-    LM_TICK(4)
-    float mel[NMELS];
-    project<NMELS>(mag, ct, mel);
-
-    const long row = (long)tile * LM_TILE_FRAMES + tid;
-    const bool valid = tid < LM_TILE_FRAMES && row < a.frame_count;
-    float ymax = -__builtin_inff(), zmin = __builtin_inff();
-#pragma unroll
-    for (int m = 0; m < NMELS; ++m) {
-      const float y = __log10f(fmaxf(mel[m], 1e-10f));
-      ymax = fmaxf(ymax, y);
-      const float z = (y + 4.0f) * 0.25f;
-      zmin = fminf(zmin, z);
-      mel[m] = z;
-    }
-    // the DMA issued above landed long ago; waiting here, before the stores, leaves the stores
-    // in flight across the loop edge (the counter cannot tell loads from stores)
-#ifdef LM_TIMING
-    asm volatile("" :: "v"(zmin), "v"(ymax));
-#endif
-    LM_TICK(5)
-    __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
-    asm volatile("" ::: "memory");
-    LM_TICK(6)
-    if (!valid) {
-      ymax = -__builtin_inff();
-      zmin = __builtin_inff();
-    }
-    // Store.  A lane holds one whole output row, so a plain store instruction would touch 64
-    // rows with 16 bytes each, and the L2 request rate (one request per 16-byte piece) would
-    // cost more time than the transform.  The four lanes of a quad therefore first transpose
-    // 4 x 4 pieces among themselves (two butterfly steps of lane-pair exchanges per register),
-    // after which lane i of the quad holds pieces i of the quad's four rows: one store
-    // instruction then writes 64 contiguous bytes per quad, a quarter of the requests.
-    {
-      const bool hi1 = lane & 1, hi2 = lane & 2;
-      const long qrow = row - (lane & 3);              // first row of this quad
-      const int qtid = tid & ~3;
-#pragma unroll
-      for (int g = 0; g < NMELS; g += 16) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float* r0 = &mel[g + c];                      // registers r0[4 j], j = piece index
-#pragma unroll
-          for (int j = 0; j < 4; j += 2) {              // exchange with lane ^ 1: pieces j, j + 1
-            const float send = hi1 ? r0[4 * j] : r0[4 * (j + 1)];
-            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
-                __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-            if (hi1) r0[4 * j] = recv; else r0[4 * (j + 1)] = recv;
-          }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {                 // exchange with lane ^ 2: pieces j, j + 2
-            const float send = hi2 ? r0[4 * j] : r0[4 * (j + 2)];
-            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
-                __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-            if (hi2) r0[4 * j] = recv; else r0[4 * (j + 2)] = recv;
-          }
-        }
-      }
-      // now mel[g + 4 j + c] = element (g + 4 (lane & 3) + c) of row qrow + j
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (qtid + j < LM_TILE_FRAMES && qrow + j < a.frame_count) {
-          float* dst = a.out + (qrow + j) * NMELS + 4 * (lane & 3);
-#pragma unroll
-          for (int g = 0; g < NMELS; g += 16)
-            *(v4f*)(dst + g) = v4f{mel[g + 4 * j], mel[g + 4 * j + 1], mel[g + 4 * j + 2], mel[g + 4 * j + 3]};
-        }
-      }
-    }
-    run_max = fmaxf(run_max, ymax);
-    zmin = wave_min(zmin);
-    if (lane == 0) a.seg_min[tile * 4 + wave] = zmin;
-    tile = next;
-    LM_TICK(7)
-  }
-#ifdef LM_TIMING
-  if (blockIdx.x == 7 && lane == 0)
-    printf("wave %d: barrier %u  edge %u  passA %u  barrier %u  passB %u  project+log %u  dma-wait %u  stores %u\n",
-           wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7]);
-#endif
-  // Piece maximum without a preset value or an extra launch: every block publishes its own
-  // maximum, takes a ticket, and the block that draws the last ticket reduces the published
-  // values and returns the ticket counter to zero for the next launch.
-  run_max = wave_max(run_max);
-  block_barrier();                          // every wave has seen its last DMA land: LDS is free
-  float* red = (float*)lds;
-  if (lane == 0) red[wave] = run_max;
-  __syncthreads();
-  if (tid == 0) {
-    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __hip_atomic_store(a.blk_max + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[4] = t == gridDim.x - 1 ? 1.0f : 0.0f;
-  }
-  __syncthreads();
-  if (red[4] != 0.0f && wave == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    float m = -__builtin_inff();
-    for (int i = lane; i < (int)gridDim.x; i += 64)
-      m = fmaxf(m, __hip_atomic_load(a.blk_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    m = wave_max(m);
-    if (lane == 0) {
-      *a.piece_max = m;
-      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// Segment s = (tile, wave) covers rows [tile*247 + 64*wave, +64) of that tile.
-__global__ __launch_bounds__(256)
-void logmel_finalize(float* __restrict__ out, long n_frames, int n_mels, int n_segments,
-                     const float* __restrict__ gmax, const float* __restrict__ seg_min) {
-  const float zc = ((*gmax - 8.0f) + 4.0f) * 0.25f;
-  for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
-    if (!(seg_min[s] < zc)) continue;
-    const int tile = s >> 2, wave = s & 3;
-    long r0 = (long)tile * LM_TILE_FRAMES + 64 * wave;
-    long r1 = r0 + 64;
-    const long tile_end = (long)(tile + 1) * LM_TILE_FRAMES;
-    r1 = r1 > tile_end ? tile_end : r1;
-    r1 = r1 > n_frames ? n_frames : r1;
-    const long e0 = r0 * n_mels, e1 = r1 * n_mels;      // multiples of 4 (n_mels % 4 == 0)
-    for (long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * 256) {
-      v4f v = *(v4f*)(out + e);
-      v.x = fmaxf(v.x, zc); v.y = fmaxf(v.y, zc); v.z = fmaxf(v.z, zc); v.w = fmaxf(v.w, zc);
-      *(v4f*)(out + e) = v;
-    }
-  }
-}
-
 
 // =============================================================================================
 // Two lanes per frame (lane l and lane l + 32 of a wave): the state a lane carries through the
 // transform is 200 floats, the kernel fits 256 registers and two waves share a SIMD, so one
 // wave's scalar instructions, waits and hazards issue under the other's arithmetic.  A 256-lane
 // workgroup owns a tile of 118 frames (80 KB of LDS: two workgroups per CU); the dataflow inside
-// a lane pair is described in gen_logmel2.py.
+// a lane pair is described in gen_logmel.py.
 // =============================================================================================
-__device__ __forceinline__ void lm2_swap(float& vdst, float& src0) {
+__device__ __forceinline__ void lm_swap(float& vdst, float& src0) {
   // v_permlane32_swap: vdst of lanes 32..63 <-> src0 of lanes 0..31.  Written as an asm statement
   // because __builtin_amdgcn_permlane32_swap loses its second result in this compiler (both
   // elements of the returned pair read the first one); the leading s_nop covers the two wait
@@ -417,7 +100,7 @@ __device__ __forceinline__ void lm2_swap(float& vdst, float& src0) {
 }
 
 // four swaps behind one leading s_nop (the operands of the later ones are older still)
-__device__ __forceinline__ void lm2_swap4(float& v0, float& s0, float& v1, float& s1, float& v2, float& s2,
+__device__ __forceinline__ void lm_swap4(float& v0, float& s0, float& v1, float& s1, float& v2, float& s2,
                                           float& v3, float& s3) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
       "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
@@ -428,7 +111,7 @@ __device__ __forceinline__ void lm2_swap4(float& v0, float& s0, float& v1, float
 // parts in their two halves, cs = (cos, sin) with W = cos - i sin.  The two sequences are
 // interleaved: a packed result may not be consumed by the very next instruction, and the compiler
 // does not pad hazards inside (or right after) an asm statement.
-__device__ __forceinline__ void lm2_combine2(v2f csa, v2f ra, v2f ia, v2f& ma, v2f csb, v2f rb, v2f ib,
+__device__ __forceinline__ void lm_combine2(v2f csa, v2f ra, v2f ia, v2f& ma, v2f csb, v2f rb, v2f ib,
                                              v2f& mb) {
   v2f ta, tb, ja, jb;
   asm("s_nop 0\n\t"
@@ -449,24 +132,27 @@ __device__ __forceinline__ void lm2_combine2(v2f csa, v2f ra, v2f ia, v2f& ma, v
       : [csa] "v"(csa), [ra] "v"(ra), [ia] "v"(ia), [csb] "v"(csb), [rb] "v"(rb), [ib] "v"(ib));
 }
 
-#include "logmel2_codelet.inc"
+#include "logmel_codelet.inc"
 
-#define LM2_TILE_FRAMES 118
-#define LM2_ROWS (LM2_TILE_FRAMES + 2)
-#define LM2_ROW_BYTES (LM_PITCH * 4)
-#define LM2_TABLE_OFF (LM2_ROWS * LM2_ROW_BYTES)                      // 78720
-#define LM2_LDS_TABLE_BYTES (LOGMEL2_WIN_BYTES + LOGMEL2_TW_BYTES)    // 2912
-#define LM2_LDS_BYTES 81920
-#define LM2_PIECES (LM2_ROWS * LM_CHUNKS_PER_ROW)
-#define LM2_DMA_PER_WAVE ((LM2_PIECES + 255) / 256)
-#define LM2_ROW_DMA_PER_WAVE ((LM2_ROWS + 3) / 4)
+#define LM_TILE_FRAMES 118
+#define LM_ROWS (LM_TILE_FRAMES + 2)
+#define LM_ROW_BYTES (LM_PITCH * 4)
+#define LM_TABLE_OFF (LM_ROWS * LM_ROW_BYTES)                      // 78720
+#define LM_LDS_TABLE_BYTES (LOGMEL_WIN_BYTES + LOGMEL_TW_BYTES)    // 2912
+#define LM_PIECES (LM_ROWS * LM_CHUNKS_PER_ROW)
+#define LM_DMA_PER_WAVE ((LM_PIECES + 255) / 256)
+#define LM_ROW_DMA_PER_WAVE ((LM_ROWS + 3) / 4)
 
-// Lane-clamped transfer of a tile's span (see issue_tile_dma); pieces past the last row are not
-// written: the tables live there.
-__device__ __forceinline__ void issue_tile_dma2(const float* __restrict__ pcm, int g0r, int hi_r,
+// Lane-clamped transfer of one tile's PCM span into LDS: instruction inst = wave + 4 i writes
+// 1 KiB = 64 pieces of 16 bytes; LDS piece q = row q / 41, piece q % 41 of that row (the pad piece
+// of a row re-reads the row's last data piece).  g0r = index, relative to pcm[0], of the tile's
+// first sample (may be negative); source indices are clamped into [0, hi_r - 4] (hi_r a multiple
+// of 4, so every piece is a 16-byte aligned load); what lies outside is repaired by
+// patch_reflect().  Pieces past the last row are not written.
+__device__ __forceinline__ void issue_tile_dma(const float* __restrict__ pcm, int g0r, int hi_r,
                                                 unsigned char* lds, int wave, int lane) {
 #pragma unroll 4
-  for (int i = 0; i < LM2_DMA_PER_WAVE; ++i) {
+  for (int i = 0; i < LM_DMA_PER_WAVE; ++i) {
     const int inst = wave + 4 * i;
     const int q = inst * 64 + lane;
     const int r = q / LM_CHUNKS_PER_ROW;
@@ -475,32 +161,39 @@ __device__ __forceinline__ void issue_tile_dma2(const float* __restrict__ pcm, i
     int s = g0r + r * LM_HOP + 4 * cc;
     s = s > hi_r - 4 ? hi_r - 4 : s;
     s = s < 0 ? 0 : s;
-    if (q < LM2_PIECES)
+    if (q < LM_PIECES)
       __builtin_amdgcn_global_load_lds((glb_void*)((const char*)pcm + (unsigned)(s * 4)),
                                        (lds_void*)(lds + inst * 1024), 16, 0, 0);
   }
 }
 
-// One instruction per LDS row (see issue_rows_dma); the last row's instruction keeps the lanes
-// that would spill into the tables switched off.
-__device__ __forceinline__ void issue_rows_dma2(const RowDma& d, int wave, int ln, int i0, int i1) {
+// The same transfer for a tile whose span, plus one row of slack, lies inside [0, hi_r): one
+// instruction per LDS row, rows wave, wave + 4, ...  An instruction covers 1024 LDS bytes, a
+// row 656, so lanes 41..63 land on pieces 0..22 of the following row and fetch exactly the
+// samples that belong there (lane 40 fills the pad piece); whichever instruction writes a
+// byte last writes the same value.  Source and destination are uniform per instruction, so
+// issuing costs scalar work only.  The last instalments clamp to the last row, whose
+// instruction keeps lanes 41..63 switched off (they would write past the rows).
+__device__ __forceinline__ void issue_rows_dma(const RowDma& d, int wave, int ln, int i0, int i1) {
 #pragma unroll
   for (int i = i0; i < i1; ++i) {
     int di = 4 * i;
-    if (4 * i + 3 >= LM2_ROWS) di = min(di, LM2_ROWS - 1 - wave);
-    const bool last = wave + di == LM2_ROWS - 1;             // wave-uniform
+    if (4 * i + 3 >= LM_ROWS) di = min(di, LM_ROWS - 1 - wave);
+    const bool last = wave + di == LM_ROWS - 1;             // wave-uniform
     if (!last || ln < 41)
       __builtin_amdgcn_global_load_lds((glb_void*)(d.base + (long)di * (LM_HOP * 4) + d.lane_off),
-                                       (lds_void*)(size_t)(d.lds0 + di * LM2_ROW_BYTES), 16, 0, 0);
+                                       (lds_void*)(size_t)(d.lds0 + di * LM_ROW_BYTES), 16, 0, 0);
   }
 }
 
-__device__ __forceinline__ void patch_reflect2(const float* __restrict__ pcm, long origin, long n_total,
+// Reflect padding (np.pad mode='reflect', stft.py:251-255): the samples before
+// the clip start and after its end, as far as a valid frame can reach.
+__device__ __forceinline__ void patch_reflect(const float* __restrict__ pcm, long origin, long n_total,
                                                long hi_al, long g0, float* lds, int tid) {
   if (tid < 200) {
     const long g = -200 + tid;
     const long i = g - g0;
-    if (i >= 0 && i < (long)LM2_ROWS * LM_HOP) {
+    if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
       const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
       lds[r * LM_PITCH + c] = pcm[-g - origin];
     }
@@ -508,7 +201,7 @@ __device__ __forceinline__ void patch_reflect2(const float* __restrict__ pcm, lo
   if (tid < 204) {
     const long g = hi_al + tid;
     const long i = g - g0;
-    if (i >= 0 && i < (long)LM2_ROWS * LM_HOP) {
+    if (i >= 0 && i < (long)LM_ROWS * LM_HOP) {
       const int r = (int)(i / LM_HOP), c = (int)(i - (long)r * LM_HOP);
       long src = g < n_total ? g : 2 * (n_total - 1) - g;
       src = src < origin ? origin : src;
@@ -518,30 +211,37 @@ __device__ __forceinline__ void patch_reflect2(const float* __restrict__ pcm, lo
 }
 
 template <int NMELS>
-struct Lm2Shape;
+struct LmShape;
 template <>
-struct Lm2Shape<80> {
-  static constexpr int kSplit = LOGMEL2_SPLIT_80, kAcc = LOGMEL2_NACC_80;
+struct LmShape<80> {
+  static constexpr int kSplit = LOGMEL_SPLIT_80, kAcc = LOGMEL_NACC_80;
   static __device__ __forceinline__ void project(float (&mg)[104], lm_const_ptr ct, bool upper, float (&acc)[kAcc]) {
-    logmel2_project_80(mg, ct, upper, acc);
+    logmel_project_80(mg, ct, upper, acc);
   }
 };
 template <>
-struct Lm2Shape<128> {
-  static constexpr int kSplit = LOGMEL2_SPLIT_128, kAcc = LOGMEL2_NACC_128;
+struct LmShape<128> {
+  static constexpr int kSplit = LOGMEL_SPLIT_128, kAcc = LOGMEL_NACC_128;
   static __device__ __forceinline__ void project(float (&mg)[104], lm_const_ptr ct, bool upper, float (&acc)[kAcc]) {
-    logmel2_project_128(mg, ct, upper, acc);
+    logmel_project_128(mg, ct, upper, acc);
   }
 };
+
+// -DLM_TIMING: per-phase cycle stamps, printed by one block (development builds only)
+#ifdef LM_TIMING
+#define LM_TICK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define LM_TICK(i)
+#endif
 
 template <int NMELS, bool BULK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logmel_pair(const LogmelArgs a) {
   // two objects, so that the compiler does not order the table reads of the second pass behind
   // the transfers that refill the rows (it would wait for every instalment to land)
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM2_TABLE_OFF];
-  __shared__ __attribute__((aligned(16))) unsigned char tabs[LM2_LDS_TABLE_BYTES];
-  constexpr int kSplit = Lm2Shape<NMELS>::kSplit, kAcc = Lm2Shape<NMELS>::kAcc;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LM_TABLE_OFF];
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[LM_LDS_TABLE_BYTES];
+  constexpr int kSplit = LmShape<NMELS>::kSplit, kAcc = LmShape<NMELS>::kAcc;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -552,17 +252,17 @@ void logmel_pair(const LogmelArgs a) {
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
   const int hi_r = (int)(a.hi_al - a.origin);
-  issue_tile_dma2(a.pcm, (int)((a.frame_begin + (long)tile * LM2_TILE_FRAMES) * LM_HOP - 200 - a.origin),
+  issue_tile_dma(a.pcm, (int)((a.frame_begin + (long)tile * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin),
                   hi_r, lds, wave, lane);
-  if (tid < LM2_LDS_TABLE_BYTES / 16)
+  if (tid < LM_LDS_TABLE_BYTES / 16)
     *(v4f*)(tabs + 16 * tid) = *(const v4f*)(a.lds_table + 4 * tid);
   __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
   __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
 
-  const int fslot = slot < LM2_TILE_FRAMES ? slot : LM2_TILE_FRAMES - 1;
-  const unsigned char* base = lds + fslot * LM2_ROW_BYTES + (upper ? 8 : 0);
-  const unsigned char* wt = tabs + (upper ? LOGMEL2_WIN_BYTES / 2 : 0);
-  const unsigned char* tt = tabs + LOGMEL2_WIN_BYTES + (upper ? LOGMEL2_TW_BYTES / 2 : 0);
+  const int fslot = slot < LM_TILE_FRAMES ? slot : LM_TILE_FRAMES - 1;
+  const unsigned char* base = lds + fslot * LM_ROW_BYTES + (upper ? 8 : 0);
+  const unsigned char* wt = tabs + (upper ? LOGMEL_WIN_BYTES / 2 : 0);
+  const unsigned char* tt = tabs + LOGMEL_WIN_BYTES + (upper ? LOGMEL_TW_BYTES / 2 : 0);
 
 #ifdef LM_TIMING
   unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -570,66 +270,66 @@ void logmel_pair(const LogmelArgs a) {
 #endif
   float run_max = -__builtin_inff();
   while (tile < a.n_tiles) {
-    const long t0 = a.frame_begin + (long)tile * LM2_TILE_FRAMES;
+    const long t0 = a.frame_begin + (long)tile * LM_TILE_FRAMES;
     const long g0 = t0 * LM_HOP - 200;
     __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
     block_barrier();                        // every wave's DMA pieces of this tile have landed
     LM_TICK(0)
-    if (g0 < 0 || g0 + (long)(LM2_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
+    if (g0 < 0 || g0 + (long)(LM_ROWS + 1) * LM_HOP > a.hi_al) {   // block-uniform: an end tile
       if (BULK) {
-        issue_tile_dma2(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane);
+        issue_tile_dma(a.pcm, (int)(g0 - a.origin), hi_r, lds, wave, lane);
         __builtin_amdgcn_s_waitcnt(LM_WAIT_VM0);
         block_barrier();
       }
-      patch_reflect2(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
+      patch_reflect(a.pcm, a.origin, a.n_total, a.hi_al, g0, (float*)lds, tid);
       __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
       block_barrier();
     }
 
-    v2f sa[LOGMEL2_N_SA];
+    v2f sa[LOGMEL_N_SA];
     LM_TICK(1)
-    logmel2_pass_a(base, wt, ct, sa);
+    logmel_pass_a(base, wt, ct, sa);
     __builtin_amdgcn_s_waitcnt(LM_WAIT_LGKM0);
     LM_TICK(2)
     block_barrier();                        // the rows may now be refilled
     LM_TICK(3)
     const int next = tile + gridDim.x;
-    int g0r_next = (int)((a.frame_begin + (long)next * LM2_TILE_FRAMES) * LM_HOP - 200 - a.origin);
-    if (!BULK && next < a.n_tiles) issue_tile_dma2(a.pcm, g0r_next, hi_r, lds, wave, lane);
-    g0r_next = min(max(g0r_next, 0), hi_r - (LM2_ROWS + 1) * LM_HOP);
+    int g0r_next = (int)((a.frame_begin + (long)next * LM_TILE_FRAMES) * LM_HOP - 200 - a.origin);
+    if (!BULK && next < a.n_tiles) issue_tile_dma(a.pcm, g0r_next, hi_r, lds, wave, lane);
+    g0r_next = min(max(g0r_next, 0), hi_r - (LM_ROWS + 1) * LM_HOP);
     float mg[104];
     // The next tile's rows are requested in four instalments between the families (scalar code
     // only, rebuilt each time so that nothing stays live across the register-starved sections).
-    logmel2_pass_b(ct, tt, sa, mg, [&](int f) __attribute__((always_inline)) {
+    logmel_pass_b(ct, tt, sa, mg, [&](int f) __attribute__((always_inline)) {
       constexpr int kEvery = 13 / LM_DMA_PARTS;
       if (BULK && f % kEvery == 0 && f / kEvery < LM_DMA_PARTS) {
         const int part = f / kEvery;
         RowDma rd;
         rd.base = (const char*)a.pcm + ((long)g0r_next + wave * LM_HOP) * 4;
-        rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * LM2_ROW_BYTES;
+        rd.lds0 = (unsigned)(size_t)(lds_void*)lds + wave * LM_ROW_BYTES;
         const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
         rd.lane_off = ln * 16 - (ln >= 40 ? 16 : 0);
-        issue_rows_dma2(rd, wave, ln, (LM2_ROW_DMA_PER_WAVE * part) / LM_DMA_PARTS,
-                        (LM2_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
+        issue_rows_dma(rd, wave, ln, (LM_ROW_DMA_PER_WAVE * part) / LM_DMA_PARTS,
+                        (LM_ROW_DMA_PER_WAVE * (part + 1)) / LM_DMA_PARTS);
       }
     });
-#ifdef LM2_DEBUG       // development build only: keeps all of sa alive through the second pass
+#ifdef LM_DEBUG       // development build only: keeps all of sa alive through the second pass
     if (a.dbg && tile == 0) {
       float* d = a.dbg + tid * 512;
 #pragma unroll
-      for (int i = 0; i < LOGMEL2_N_SA; ++i) { d[2 * i] = sa[i].x; d[2 * i + 1] = sa[i].y; }
+      for (int i = 0; i < LOGMEL_N_SA; ++i) { d[2 * i] = sa[i].x; d[2 * i + 1] = sa[i].y; }
 #pragma unroll
       for (int i = 0; i < 104; ++i) d[200 + i] = mg[i];
     }
 #endif
     LM_TICK(4)
     float mel[kAcc];
-    Lm2Shape<NMELS>::project(mg, ct, upper, mel);
+    LmShape<NMELS>::project(mg, ct, upper, mel);
 #ifdef LM_TIMING
     asm volatile("" :: "v"(mel[0]), "v"(mel[kAcc - 1]), "v"(mel[7]));
 #endif
     LM_TICK(5)
-#ifdef LM2_DEBUG
+#ifdef LM_DEBUG
     if (a.dbg && tile == 0) {
       float* d = a.dbg + tid * 512;
 #pragma unroll
@@ -637,38 +337,39 @@ void logmel_pair(const LogmelArgs a) {
     }
 #endif
 
-    const long row = (long)tile * LM2_TILE_FRAMES + slot;
-    const bool valid = slot < LM2_TILE_FRAMES && row < a.frame_count;
-    float ymax = -__builtin_inff(), zmin = __builtin_inff();
+    const long row = (long)tile * LM_TILE_FRAMES + slot;
+    const bool valid = slot < LM_TILE_FRAMES && row < a.frame_count;
+    // log10, scaling, then the store, sixteen columns at a time.  The lower lane of a pair holds
+    // columns [0, kSplit) of its frame's row, the upper lane the rest.  Four neighbouring lanes
+    // (four consecutive frames, same half) transpose 4 x 4 16-byte pieces so that a store
+    // instruction writes 64 contiguous bytes per quad; a group's four stores are issued as soon
+    // as it is transposed, so the stores are spread over the whole section instead of meeting
+    // every other workgroup's stores at the memory side in one burst.
+    // extremes of the row piece: log10 and the scaling are monotone in float arithmetic, so they are
+    // taken on the projection sums and pushed through the same two expressions once
+    float pmax = mel[0], pmin = mel[0];
 #pragma unroll
-    for (int m = 0; m < kAcc; ++m) {
-      // log10 = log2 x log10(2), as __log10f computes it; its denormal pre-scaling is left out (the
-      // argument is at least 1e-10)
-      const float y = __builtin_amdgcn_logf(fmaxf(mel[m], 1e-10f)) * 0.3010299956639812f;
-      ymax = fmaxf(ymax, y);
-      const float z = (y + 4.0f) * 0.25f;
-      zmin = fminf(zmin, z);
-      mel[m] = z;
+    for (int m = 1; m < kAcc; ++m) {
+      pmax = fmaxf(pmax, mel[m]);
+      pmin = fminf(pmin, mel[m]);
     }
-    if (!valid) {
-      ymax = -__builtin_inff();
-      zmin = __builtin_inff();
-    }
-#ifdef LM_TIMING
-    asm volatile("" :: "v"(zmin), "v"(ymax), "v"(mel[0]), "v"(mel[kAcc - 1]));
-#endif
-    LM_TICK(6)
-    LM_TICK(8)
-    // Store: the lower lane of a pair holds columns [0, kSplit) of its frame's row, the upper lane
-    // the rest.  Four neighbouring lanes (four consecutive frames, same half) transpose 4 x 4
-    // 16-byte pieces so that a store instruction writes 64 contiguous bytes per quad.
+    float ymax = __builtin_amdgcn_logf(fmaxf(pmax, 1e-10f)) * 0.3010299956639812f;
+    float zmin = (__builtin_amdgcn_logf(fmaxf(pmin, 1e-10f)) * 0.3010299956639812f + 4.0f) * 0.25f;
     {
       const bool hi1 = lane & 1, hi2 = lane & 2;
       const long qrow = row - (lane & 3);
       const int qslot = slot & ~3;
       const int my_cols = upper ? NMELS - kSplit : kSplit;
+      float* dst0 = a.out + qrow * NMELS + (upper ? kSplit : 0) + 4 * (lane & 3);
 #pragma unroll
       for (int g = 0; g < kAcc; g += 16) {
+#pragma unroll
+        for (int m = g; m < g + 16; ++m) {
+          // log10 = log2 x log10(2), as __log10f computes it; its denormal pre-scaling is left out
+          // (the argument is at least 1e-10)
+          const float y = __builtin_amdgcn_logf(fmaxf(mel[m], 1e-10f)) * 0.3010299956639812f;
+          mel[m] = (y + 4.0f) * 0.25f;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float* r0 = &mel[g + c];
@@ -687,22 +388,18 @@ void logmel_pair(const LogmelArgs a) {
             if (hi2) r0[4 * j] = recv; else r0[4 * (j + 2)] = recv;
           }
         }
-      }
-#ifdef LM_TIMING
-      asm volatile("" :: "v"(mel[0]), "v"(mel[kAcc - 1]), "v"(mel[5]));
-#endif
-      LM_TICK(9)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (qslot + j < LM2_TILE_FRAMES && qrow + j < a.frame_count) {
-          float* dst = a.out + (qrow + j) * NMELS + (upper ? kSplit : 0) + 4 * (lane & 3);
-#pragma unroll
-          for (int g = 0; g < kAcc; g += 16)
-            if (g < my_cols)
-              *(v4f*)(dst + g) = v4f{mel[g + 4 * j], mel[g + 4 * j + 1], mel[g + 4 * j + 2], mel[g + 4 * j + 3]};
-        }
+        for (int j = 0; j < 4; ++j)
+          if (g < my_cols && qslot + j < LM_TILE_FRAMES && qrow + j < a.frame_count)
+            *(v4f*)(dst0 + (long)j * NMELS + g) =
+                v4f{mel[g + 4 * j], mel[g + 4 * j + 1], mel[g + 4 * j + 2], mel[g + 4 * j + 3]};
       }
     }
+    if (!valid) {
+      ymax = -__builtin_inff();
+      zmin = __builtin_inff();
+    }
+    LM_TICK(6)
     run_max = fmaxf(run_max, ymax);
     zmin = wave_min(zmin);
     if (lane == 0) a.seg_min[tile * 4 + wave] = zmin;
@@ -742,15 +439,15 @@ void logmel_pair(const LogmelArgs a) {
 
 // Segment s = (tile, wave) covers rows [tile * 118 + 32 * wave, + 32) of that tile.
 __global__ __launch_bounds__(256)
-void logmel_finalize2(float* __restrict__ out, long n_frames, int n_mels, int n_segments,
+void logmel_finalize(float* __restrict__ out, long n_frames, int n_mels, int n_segments,
                       const float* __restrict__ gmax, const float* __restrict__ seg_min) {
   const float zc = ((*gmax - 8.0f) + 4.0f) * 0.25f;
   for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
     if (!(seg_min[s] < zc)) continue;
     const int tile = s >> 2, wave = s & 3;
-    long r0 = (long)tile * LM2_TILE_FRAMES + 32 * wave;
+    long r0 = (long)tile * LM_TILE_FRAMES + 32 * wave;
     long r1 = r0 + 32;
-    const long tile_end = (long)(tile + 1) * LM2_TILE_FRAMES;
+    const long tile_end = (long)(tile + 1) * LM_TILE_FRAMES;
     r1 = r1 > tile_end ? tile_end : r1;
     r1 = r1 > n_frames ? n_frames : r1;
     const long e0 = r0 * n_mels, e1 = r1 * n_mels;
@@ -767,17 +464,15 @@ __global__ void logmel_init(float* piece_max) { *piece_max = -__builtin_inff(); 
 // ------------------------------------------------------------------ host side
 #include "../../include/stt_mi355x.h"
 #include "logmel_tables.h"
-#include "logmel2_tables.h"
 #include "stt_common.h"
-#include <cstdlib>
+#include <vector>
 
 struct stt_logmel_plan {
   int n_mels;
   int device;
   int n_cu;
-  float* d_table;
-  float* d_table2;       // two-lanes-per-frame kernel: DFT constants + mel weights (scalar loads)
-  float* d_lds_table;    // ... and the window / twiddle tables it copies into LDS
+  float* d_table;        // DFT constants + mel weights (scalar loads), then the LDS tables
+  float* d_lds_table;    // window / twiddle tables every workgroup copies into LDS (inside d_table)
   unsigned* d_sync;      // [0] ticket counter, [64..] one float per block; zeroed at creation
   void* d_static_ws;     // this device's copy of lm_static_ws (address looked up at creation)
 };
@@ -787,21 +482,14 @@ struct stt_logmel_plan {
 // that the call needs no allocation.  Every GPU the library runs on holds its own copy at its
 // own address; host code reaches it only through the pointer hipGetSymbolAddress returned for
 // the current device (the array's name is a host-side stand-in, not a device address).
-#define LM_STATIC_WS_BYTES 65536
+#define LM_STATIC_WS_BYTES 131072
 static __device__ __align__(256) unsigned char lm_static_ws[LM_STATIC_WS_BYTES];
 
 static const size_t kWsHeader = 256;      // piece maximum lives in the first float
 static const size_t kWsPadPcm = 512 * sizeof(float);
 
-// STT_MI355X_LOGMEL=pair selects the two-lanes-per-frame kernel (under development: parity-green,
-// not yet faster than the one-lane-per-frame kernel)
-static bool lm_pair() {
-  static const bool v = getenv("STT_MI355X_LOGMEL") && getenv("STT_MI355X_LOGMEL")[0] == 'p';
-  return v;
-}
-static int tile_frames() { return lm_pair() ? LM2_TILE_FRAMES : LM_TILE_FRAMES; }
 static int tiles_for(int64_t frames) {
-  return (int)((frames + tile_frames() - 1) / tile_frames());
+  return (int)((frames + LM_TILE_FRAMES - 1) / LM_TILE_FRAMES);
 }
 
 static float* g_lm_debug = nullptr;
@@ -841,37 +529,22 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
                         "mel basis has a non-zero at (bin %d, filter %d) outside the Slaney "
                         "16 kHz / 400-point / 0-8000 Hz structure this kernel is built for", k, m);
 
-  std::vector<float> table(LOGMEL_TABLE_LEN, 0.0f);
+  // scalar-load table, rounded up so that the LDS tables behind it stay 16-byte aligned
+  const size_t n_scalar = (LOGMEL_TABLE_LEN + 3) & ~(size_t)3;
+  std::vector<float> table(n_scalar + LM_LDS_TABLE_BYTES / 4, 0.0f);
   for (int i = 0; i < LOGMEL_N_FFT_CONSTS; ++i) table[LOGMEL_OFF_FFT + i] = logmel_fft_consts[i];
-  // window sample s = 2 a + h is input a / 8 of sub-DFT a % 8: stored in consumption order
-  for (int i = 0; i < LM_NFFT; ++i) {
-    const int a2 = i / 2;
-    table[LOGMEL_OFF_WIN + 2 * (25 * (a2 % 8) + a2 / 8) + (i & 1)] = window[i];
-  }
-  for (int k = 0; k <= 100; ++k) {
-    const double th = 2.0 * 3.14159265358979323846 * k / 400.0;
-    table[LOGMEL_OFF_TW + 2 * k] = (float)cos(th);
-    table[LOGMEL_OFF_TW + 2 * k + 1] = (float)sin(th);
-  }
-  for (int i = 0; i < nnz; ++i)
-    table[off_mel + i] = mel_basis[(size_t)nz[i][0] * n_mels + nz[i][1]];
-
-  // tables of the two-lanes-per-frame kernel
-  const int nnz2 = n_mels == 80 ? LOGMEL2_NNZ_80 : LOGMEL2_NNZ_128;
-  const unsigned short (*nz2)[2] = n_mels == 80 ? logmel2_nz_80 : logmel2_nz_128;
-  const int off_mel2 = n_mels == 80 ? LOGMEL2_OFF_MEL80 : LOGMEL2_OFF_MEL128;
-  std::vector<float> table2((LOGMEL2_TABLE_LEN + 3) & ~3, 0.0f);      // the LDS tables behind it stay 16-byte aligned
-  for (int i = 0; i < LOGMEL2_N_FFT_CONSTS; ++i) table2[LOGMEL2_OFF_FFT + i] = logmel2_fft_consts[i];
-  for (int i = 0; i < nnz2; ++i) table2[off_mel2 + i] = mel_basis[(size_t)nz2[i][0] * n_mels + nz2[i][1]];
-  std::vector<float> lds_table(LM2_LDS_TABLE_BYTES / 4, 0.0f);
+  for (int i = 0; i < nnz; ++i) table[off_mel + i] = mel_basis[(size_t)nz[i][0] * n_mels + nz[i][1]];
+  // window: per lane half and sub-DFT j, the pairs (w[4m + 2 half], w[4m + 2 half + 1]) of the
+  // inputs m = j + 4 m2 in the order the sub-DFT consumes them (26 slots, the last one padding)
+  float* lds_table = table.data() + n_scalar;
   for (int half = 0; half < 2; ++half)
     for (int j = 0; j < 4; ++j)
-      for (int pos = 0; pos < 25; ++pos) {         // pairs in the order the sub-DFT consumes them
-        const int m = j + 4 * logmel2_win_pos[j][pos], at = 2 * (half * 104 + 26 * j + pos);
+      for (int pos = 0; pos < 25; ++pos) {
+        const int m = j + 4 * logmel_win_pos[j][pos], at = 2 * (half * 104 + 26 * j + pos);
         lds_table[at] = window[4 * m + 2 * half];
         lds_table[at + 1] = window[4 * m + 2 * half + 1];
       }
-  for (int i = 0; i < LOGMEL2_TW_BYTES / 4; ++i) lds_table[LOGMEL2_WIN_BYTES / 4 + i] = logmel2_twiddles[i];
+  for (int i = 0; i < LOGMEL_TW_BYTES / 4; ++i) lds_table[LOGMEL_WIN_BYTES / 4 + i] = logmel_twiddles[i];
 
   stt_logmel_plan* p = new stt_logmel_plan();
   p->n_mels = n_mels;
@@ -880,18 +553,10 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
   STT_HIP_OR_FAIL(hipGetDeviceProperties(&prop, p->device), delete p);
   p->n_cu = prop.multiProcessorCount;
   STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table, table.size() * sizeof(float)), delete p);
+  p->d_lds_table = p->d_table + n_scalar;
   STT_HIP_OR_FAIL(hipMemcpy(p->d_table, table.data(), table.size() * sizeof(float),
                             hipMemcpyHostToDevice), ((void)hipFree(p->d_table), delete p));
-  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_table2, (table2.size() + lds_table.size()) * sizeof(float)),
-                  ((void)hipFree(p->d_table), delete p));
-  p->d_lds_table = p->d_table2 + table2.size();
-  STT_HIP_OR_FAIL(hipMemcpy(p->d_table2, table2.data(), table2.size() * sizeof(float), hipMemcpyHostToDevice),
-                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
-  STT_HIP_OR_FAIL(hipMemcpy(p->d_lds_table, lds_table.data(), lds_table.size() * sizeof(float),
-                            hipMemcpyHostToDevice),
-                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
-  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4),
-                  ((void)hipFree(p->d_table2), (void)hipFree(p->d_table), delete p));
+  STT_HIP_OR_FAIL(hipMalloc((void**)&p->d_sync, (64 + 1024) * 4), ((void)hipFree(p->d_table), delete p));
   STT_HIP_OR_FAIL(hipMemset(p->d_sync, 0, (64 + 1024) * 4),
                   ((void)hipFree(p->d_sync), (void)hipFree(p->d_table), delete p));
   // the plan belongs to the current device: look up that device's copy of the static workspace
@@ -904,7 +569,6 @@ int stt_logmel_plan_create(int n_mels, const float* window, const float* mel_bas
 void stt_logmel_plan_destroy(stt_logmel_plan* plan) {
   if (!plan) return;
   (void)hipFree(plan->d_table);
-  (void)hipFree(plan->d_table2);
   (void)hipFree(plan->d_sync);
   delete plan;
 }
@@ -954,37 +618,19 @@ int stt_logmel_stage1(const stt_logmel_plan* plan, const float* d_pcm, int64_t s
   a.pcm = d_pcm; a.origin = sample_origin; a.lo = lo; a.hi_al = lo + ((hi - lo) & ~3L);
   a.n_total = n_total;
   a.frame_begin = frame_begin; a.frame_count = frame_count; a.n_tiles = n_tiles;
-  a.ct = plan->d_table; a.out = d_mel; a.piece_max = d_piece_max;
+  a.ct = plan->d_table; a.lds_table = plan->d_lds_table; a.out = d_mel; a.piece_max = d_piece_max;
   a.seg_min = (float*)((char*)d_workspace + kWsHeader);
   a.ticket = plan->d_sync; a.blk_max = (float*)(plan->d_sync + 64);
-  if (lm_pair()) {
-    a.ct = plan->d_table2;
-    a.lds_table = plan->d_lds_table;
-    a.dbg = g_lm_debug;
-    int grid = n_tiles < 2 * plan->n_cu ? n_tiles : 2 * plan->n_cu;      // two workgroups per CU
-    grid = grid < 1024 ? grid : 1024;
-    const bool bulk = a.hi_al - a.origin >= (long)(LM2_ROWS + 1) * LM_HOP;
-    if (plan->n_mels == 80) {
-      if (bulk) hipLaunchKernelGGL((logmel_pair<80, true>), dim3(grid), dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL((logmel_pair<80, false>), dim3(grid), dim3(256), 0, stream, a);
-    } else {
-      if (bulk) hipLaunchKernelGGL((logmel_pair<128, true>), dim3(grid), dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL((logmel_pair<128, false>), dim3(grid), dim3(256), 0, stream, a);
-    }
-    STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
-    return STT_OK;
-  }
-  a.lds_table = nullptr;
-  a.dbg = nullptr;
-  int grid = n_tiles < plan->n_cu ? n_tiles : plan->n_cu;
-  grid = grid < 1024 ? grid : 1024;
+  a.dbg = g_lm_debug;
+  int grid = n_tiles < 2 * plan->n_cu ? n_tiles : 2 * plan->n_cu;      // two workgroups per CU
+  grid = grid < 1024 ? grid : 1024;                                    // one blk_max slot per block
   const bool bulk = a.hi_al - a.origin >= (long)(LM_ROWS + 1) * LM_HOP;
   if (plan->n_mels == 80) {
-    if (bulk) hipLaunchKernelGGL((logmel_main<80, true>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((logmel_main<80, false>), dim3(grid), dim3(256), 0, stream, a);
+    if (bulk) hipLaunchKernelGGL((logmel_pair<80, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logmel_pair<80, false>), dim3(grid), dim3(256), 0, stream, a);
   } else {
-    if (bulk) hipLaunchKernelGGL((logmel_main<128, true>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((logmel_main<128, false>), dim3(grid), dim3(256), 0, stream, a);
+    if (bulk) hipLaunchKernelGGL((logmel_pair<128, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logmel_pair<128, false>), dim3(grid), dim3(256), 0, stream, a);
   }
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
@@ -998,14 +644,9 @@ int stt_logmel_stage2(const stt_logmel_plan* plan, float* d_mel, int64_t frame_c
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   const int n_seg = tiles_for(frame_count) * 4;
   const int grid = n_seg < 2048 ? n_seg : 2048;
-  if (lm_pair())
-    hipLaunchKernelGGL(logmel_finalize2, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
-                       plan->n_mels, n_seg, d_clip_max,
-                       (const float*)((const char*)d_workspace + kWsHeader));
-  else
-    hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
-                       plan->n_mels, n_seg, d_clip_max,
-                       (const float*)((const char*)d_workspace + kWsHeader));
+  hipLaunchKernelGGL(logmel_finalize, dim3(grid), dim3(256), 0, stream, d_mel, (long)frame_count,
+                     plan->n_mels, n_seg, d_clip_max,
+                     (const float*)((const char*)d_workspace + kWsHeader));
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
 }
@@ -1040,7 +681,7 @@ int stt_logmel_run(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_sa
 int64_t stt_logmel_static_max_samples(void) {
   // largest n with stt_logmel_workspace_bytes(n) <= LM_STATIC_WS_BYTES
   const int64_t tiles = (int64_t)(LM_STATIC_WS_BYTES - kWsHeader - kWsPadPcm) / (4 * sizeof(float)) / 64 * 64;
-  return tiles * tile_frames() * LM_HOP;
+  return tiles * LM_TILE_FRAMES * LM_HOP;
 }
 
 int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,

@@ -26,7 +26,7 @@ def window_shard(n_windows, rank, world_size):
     return [w for w in range(n_windows) if w % world_size == rank]
 
 
-def frame_shard(n_frames, rank, world_size, multiple=247):
+def frame_shard(n_frames, rank, world_size, multiple=118):
     """Contiguous [begin, end) frame range of rank `rank`, cut at multiples of `multiple`
     frames (the frontend kernel's tile)."""
     per = -(-n_frames // world_size)

@@ -63,7 +63,7 @@ def test_frame_shard_covers_every_frame_once():
             for r in range(ws):
                 b, e = frame_shard(n, r, ws)
                 assert 0 <= b <= e <= n
-                assert b % 247 == 0 or b == n
+                assert b % 118 == 0 or b == n
                 seen += list(range(b, e)) if n < 5000 else [(b, e)]
             if n < 5000:
                 assert seen == list(range(n))

@@ -53,7 +53,7 @@ def test_static_workspace_rejects_long_clips():
     plan = fn._plan(dev)
     limit = lib.stt_logmel_static_max_samples()
     assert limit >= 16000 * 3600                   # an hour of audio fits
-    assert lib.stt_logmel_workspace_bytes(limit) <= 65536 < lib.stt_logmel_workspace_bytes(limit + 247 * 160 * 64)
+    assert lib.stt_logmel_workspace_bytes(limit) <= 131072 < lib.stt_logmel_workspace_bytes(limit + 118 * 160 * 64)
     pcm = torch.zeros(1024, dtype=torch.float32, device=dev)
     mel = torch.zeros(1024, dtype=torch.float32, device=dev)
     rc = lib.stt_logmel_run_static(plan, pcm.data_ptr(), limit + 1, mel.data_ptr(), None)
