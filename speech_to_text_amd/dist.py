@@ -7,7 +7,8 @@ reduction in the whole path is one float: the clip-wide maximum of the log-mel w
 clip's frontend is itself split across ranks.
 
 The reference has no multi-GPU path (everything is batch 1, sequential: models/stt/whisper.py:
-228-249); this is the MI355X-side partitioning of its per-window loop.
+228-249); this is the MI355X-side partitioning of its per-window loop.  Its default sequential
+mode does not shard inside a file: there whole files are dealt to the ranks (`transcribe_files`).
 """
 import numpy as np
 import torch
@@ -56,6 +57,39 @@ def transcribe_sharded(model, mel, *, batch_size=32, group=None, **kwargs):
     merged = gather_window_results(local, group=group)
     segments = [merged[w] for w in sorted(merged)]
     return {'text': ' '.join(s['text'] for s in segments), 'segments': segments}
+
+
+def file_shard(durations, rank, world_size):
+    """Indices of the files rank `rank` transcribes.  The sequential mode of the reference
+    (previous-text prompt and timestamp seek, models/stt/whisper.py:238-243, 296-300) makes every
+    window of a file depend on the one before, so a file is the unit that can move to another
+    GPU.  Files are dealt longest first, each to the rank with the least audio so far (ties to
+    the lowest rank): the same deal on every rank, no communication."""
+    load = [0.0] * world_size
+    mine = []
+    order = sorted(range(len(durations)), key=lambda i: (-float(durations[i]), i))
+    for i in order:
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        load[r] += float(durations[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def transcribe_files(model, files, *, durations=None, group=None, **kwargs):
+    """Every rank calls this with the same list of files (paths, arrays or dicts `model.infer`
+    accepts); each file is transcribed in the reference's sequential mode by ONE rank
+    (`file_shard`), and the per-file results are gathered on every rank, in the order of `files`.
+    `durations` (seconds, or any proxy such as file sizes) balances the deal; without it files are
+    weighed by their sample count when they are arrays and equally otherwise."""
+    rank, ws = world()
+    if durations is None:
+        durations = [len(f) if hasattr(f, '__len__') and not isinstance(f, (str, dict)) else 1.0 for f in files]
+    if len(durations) != len(files):
+        raise ValueError('durations: %d values for %d files' % (len(durations), len(files)))
+    local = {i: model.infer(files[i], **kwargs) for i in file_shard(durations, rank, ws)}
+    merged = gather_window_results(local, group=group)
+    return [merged[i] for i in range(len(files))]
 
 
 def sharded_log_mel(stft, pcm, *, group=None, gather=True):

@@ -26,6 +26,12 @@ class _StubModel(object):
                           'text': 'w%d' % w, 'lang': 'en'}
         return out
 
+    def infer(self, audio, **kw):
+        """Looks like Whisper.infer in sequential mode: one result per file, naming who ran it."""
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        return {'text': 'file of %d samples' % len(audio), 'rank': rank,
+                'segments': [{'start': 0.0, 'end': len(audio) / 16000.0}]}
+
 
 def _worker(rank, world_size, port, tmp):
     sys.path.insert(0, ROOT)
@@ -40,6 +46,12 @@ def _worker(rank, world_size, port, tmp):
     assert res['text'] == ' '.join('w%d' % w for w in range(8))
     mine = sd.window_shard(8, rank, world_size)
     assert mine == list(range(rank, 8, world_size))
+    # sequential mode: whole files are dealt to the ranks, results come back in file order
+    files = [np.zeros(16000 * s, np.float32) for s in (5, 40, 7, 33, 1)]
+    out = sd.transcribe_files(_StubModel(), files)
+    assert [o['text'] for o in out] == ['file of %d samples' % len(f) for f in files]
+    by_rank = [sum(len(f) for f, o in zip(files, out) if o['rank'] == r) for r in range(world_size)]
+    assert sorted(by_rank) == sorted([16000 * 45, 16000 * 41])          # 40 + 5 | 33 + 7 + 1
     # scalar exchange used by the split frontend
     t = torch.tensor([float(rank) - 3.0])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -71,3 +83,16 @@ def test_frame_shard_covers_every_frame_once():
                 assert seen[0][0] == 0 and seen[-1][1] == n
                 assert all(seen[i][1] == seen[i + 1][0] for i in range(ws - 1))
     assert sum(len(window_shard(1200, r, 8)) for r in range(8)) == 1200
+
+
+def test_file_shard_is_a_balanced_partition():
+    from speech_to_text_amd.dist import file_shard
+    rng = np.random.default_rng(0)
+    for n, ws in ((0, 2), (1, 4), (7, 3), (40, 8)):
+        dur = rng.uniform(1, 600, n)
+        parts = [file_shard(dur, r, ws) for r in range(ws)]
+        assert sorted(i for p in parts for i in p) == list(range(n))
+        if n >= ws:
+            loads = [sum(dur[i] for i in p) for p in parts]
+            assert max(loads) - min(loads) <= dur.max()            # longest-first greedy bound
+    assert file_shard([3, 3, 3], 0, 2) == [0, 2] and file_shard([3, 3, 3], 1, 2) == [1]
