@@ -185,6 +185,11 @@ typedef struct {
                                      top-k.  The reported score is the log-probability of the
                                      token drawn */
   uint64_t seed;                  /* of the draws: same seed, same inputs -> same tokens */
+  float* d_logits_out;            /* NULL, or device [batch][max_steps][n_vocab] float32 that receives the
+                                     processed scores (log-probabilities after temperature, filter and
+                                     log-softmax) of every step: InferenceOutput.logits with
+                                     return_logits = True (generation_utils.py:266-268, 297, 551-561).
+                                     Greedy search only; steps after an early stop are left untouched */
 } stt_generate_params;
 
 /* Generation over the last encoded batch.  prompt: host [batch][prompt_len].

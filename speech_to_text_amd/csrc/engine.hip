@@ -266,6 +266,7 @@ int alloc_buffers(stt_engine* e) {
       (rc = buf_alloc(e, &g.lengths_tmp, S)) || (rc = buf_alloc(e, &g.finished_tmp, S)) ||
       (rc = buf_alloc(e, &g.slot_of_tmp, S * L)) || (rc = buf_alloc(e, &g.scores_tmp, S))) return rc;
   g.all_finished = g.step + 16;
+  g.logits_out = nullptr;
   e->suppress_cap = 4096;
   if ((rc = buf_alloc(e, &e->d_suppress, e->suppress_cap)) ||
       (rc = buf_alloc(e, &e->d_suppress_first, e->suppress_cap))) return rc;
@@ -595,7 +596,10 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   if (p->n_suppress > e->suppress_cap || p->n_suppress_first > e->suppress_cap)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "too many suppressed tokens");
   const int n_seq = batch * beams, V = e->cfg.n_vocab, max_steps = p->max_steps;
-  GenState& gs = e->gs;
+  if (p->d_logits_out && p->method != STT_METHOD_GREEDY)
+    return stt_fail(STT_ERR_UNSUPPORTED, "d_logits_out (return_logits) is implemented for greedy search only");
+  GenState gs = e->gs;
+  gs.logits_out = p->d_logits_out;
 
   // The token step is recorded into a graph (every per-token quantity lives in device memory, so
   // the recorded launches are the same for every token) and replayed.  A stream the caller
@@ -671,7 +675,8 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   // stt_engine_reserve / destroy, which drop the cache.
   hipGraphExec_t step_exec = nullptr;
   const char* no_graph = getenv("STT_MI355X_NO_GRAPH");
-  if (max_steps > 1 && !(no_graph && no_graph[0] == '1')) {
+  // (a caller's logits buffer would be baked into the recorded launches: plain launches then)
+  if (max_steps > 1 && !(no_graph && no_graph[0] == '1') && !p->d_logits_out) {
     char key[320];
     snprintf(key, sizeof key, "%d/%d/%d/%d/%d|%d/%d/%d|%a/%d/%a/%d/%a|%d/%d/%d/%d/%d|%d/%llu",
              p->method, batch, beams, nsent, max_steps, p->eos_token, p->pad_token, p->early_stopping,

@@ -166,6 +166,11 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GenState s, cons
   const RowMask m = prepare_row(row, n_vocab, f, p, s.lengths[i], s.generated + (long)i * max_steps, t, sh);
   float mx, lse; int arg;
   row_stats(row, m, sh, shi, mx, arg, lse);
+  if (s.logits_out && t < max_steps) {    // return_logits: the log-probabilities selection works on
+    float* dst = s.logits_out + ((long)i * max_steps + t) * n_vocab;
+    for (int j = threadIdx.x; j < n_vocab; j += blockDim.x)
+      dst[j] = (j < m.lo || j >= m.hi) ? NEG_INF : row[j] - lse;
+  }
   if (p.sample) {          // a draw from softmax(row) instead of its mode
     float key = NEG_INF;
     int karg = 0x7fffffff;

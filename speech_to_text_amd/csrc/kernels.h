@@ -113,6 +113,7 @@ struct GenState {          // all device pointers; n_seq = batch * beams
   int* slot_of;            // [n_seq][max_len]
   int* step;               // [1]
   int* all_finished;       // [1]
+  float* logits_out;       // null, or [n_seq][max_steps][V]: the processed scores of every step (greedy)
   // beam search scratch
   float* cand_val;         // [batch][beams]
   int* cand_idx;           // [batch][beams]

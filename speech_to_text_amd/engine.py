@@ -44,7 +44,7 @@ class GenerateParams(C.Structure):
         ("timestamp_filter", C.c_int32), ("suppress_first", C.POINTER(C.c_int32)),
         ("n_suppress_first", C.c_int32), ("timestamp_begin", C.c_int32),
         ("max_initial_timestamp", C.c_int32), ("check_every", C.c_int32),
-        ("sample", C.c_int32), ("seed", C.c_uint64),
+        ("sample", C.c_int32), ("seed", C.c_uint64), ("d_logits_out", C.c_void_p),
     ]
 
 
@@ -177,12 +177,15 @@ class WhisperEngine(object):
 
     def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
                  eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
-                 length_power=None, logits_filter=None, check_every=8, sample=None, seed=None):
+                 length_power=None, logits_filter=None, check_every=8, sample=None, seed=None,
+                 return_logits=False):
         """`temperature` given (and not 0) means, as in the reference (generation_utils.py:538-548),
         that tokens are drawn from the categorical distribution of the processed scores instead of
         taking the argmax / top-k; `sample = False` keeps the rescaling but not the draw.  `seed`
         makes the draws repeatable (default: fresh entropy per call, like the reference's
-        unseeded `keras.random.categorical`)."""
+        unseeded `keras.random.categorical`).  `return_logits` (greedy only) appends a CUDA tensor
+        [batch, max_new_tokens, n_vocab] with the processed scores of every step to the result
+        (generation_utils.py:266-268, 297); rows of steps after an early stop are -inf."""
         prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
         if prompt.ndim == 1:
             prompt = prompt[None]
@@ -232,12 +235,21 @@ class WhisperEngine(object):
         tokens = np.empty((b, nsent, p.max_steps), dtype=np.int32)
         lengths = np.empty((b, nsent), dtype=np.int32)
         scores = np.empty((b, nsent), dtype=np.float32)
+        logits = None
         with torch.cuda.device(self.device):
+            if return_logits:
+                if beam:
+                    raise ValueError("return_logits is implemented for greedy search")
+                logits = torch.full((b, p.max_steps, self.dims["n_vocab"]), float("-inf"),
+                                    dtype=torch.float32, device=self.device)
+                p.d_logits_out = logits.data_ptr()
             _lib.check(self._lib.stt_generate(
                 self._h, C.byref(p), prompt.ctypes.data_as(C.POINTER(C.c_int32)), b, s,
                 tokens.ctypes.data_as(C.POINTER(C.c_int32)), lengths.ctypes.data_as(C.POINTER(C.c_int32)),
                 scores.ctypes.data_as(C.POINTER(C.c_float)), self._stream()))
         if not beam:
+            if return_logits:
+                return tokens[:, 0], lengths[:, 0], scores[:, 0], logits
             return tokens[:, 0], lengths[:, 0], scores[:, 0]
         return tokens, lengths, scores
 

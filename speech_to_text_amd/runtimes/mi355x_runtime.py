@@ -143,14 +143,20 @@ class MI355XRuntime(Runtime):
                  max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
                  num_sentences=1, temperature=None, length_temperature=None, length_power=None,
                  logits_filter=None, early_stopping=True, seed=None, replica=0, on_encoded=None,
-                 **_ignored):
+                 return_logits=False, return_state=False, **_ignored):
         """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
         arguments (lang, verbose, ...) are ignored, as the reference's runtimes do.
         A `temperature` switches token selection from argmax / top-k to categorical draws, as in
         the reference (generation_utils.py:538-548); `seed` makes the draws repeatable.
         `replica` selects one of several engines built from the same weights and `on_encoded(event)`
         is called once the encoder pass is enqueued (the event completes when it has run): both
-        exist so that a caller can decode one batch while another engine encodes the next."""
+        exist so that a caller can decode one batch while another engine encodes the next.
+        `return_logits` (greedy search) fills `InferenceOutput.logits` with the processed scores of
+        every step, [B, steps, V] on the GPU (generation_utils.py:266-268, 297); `return_state` is
+        refused: the decoder state is the engine's own K/V cache, which has no meaning outside it."""
+        if return_state:
+            raise ValueError('return_state: the K/V cache stays inside the engine (call the runtime '
+                             'again with the extended prompt instead)')
         if isinstance(inputs, torch.Tensor):
             mel = inputs
         else:
@@ -186,14 +192,15 @@ class MI355XRuntime(Runtime):
                 ev = torch.cuda.Event()
                 ev.record()
                 on_encoded(ev)
-            toks, lengths, scores = eng.generate(
+            out = eng.generate(
                 tokens, method=method, num_beams=num_beams, num_sentences=num_sentences,
                 max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
                 early_stopping=early_stopping, temperature=temperature,
                 length_temperature=length_temperature, length_power=length_power,
-                logits_filter=logits_filter, seed=seed)
-        return InferenceOutput(tokens=toks, lengths=lengths, scores=scores, logits=None, state=None,
-                               attention_weights=None)
+                logits_filter=logits_filter, seed=seed, return_logits=bool(return_logits))
+        toks, lengths, scores = out[:3]
+        return InferenceOutput(tokens=toks, lengths=lengths, scores=scores,
+                               logits=out[3] if return_logits else None, state=None, attention_weights=None)
 
     # -- callables used by detect_language --------------------------------
     def encoder(self, mel, training=False, **_):

@@ -45,11 +45,14 @@ def rel_l2(a, b):
 
 
 def check_greedy_steps(oracle, enc, prompt, tokens, eos, pad, logits_filter=None,
-                       temperature=None, length_temperature=None, scores=None):
+                       temperature=None, length_temperature=None, scores=None, engine_logits=None):
     """Teacher-forces the oracle on the engine's greedy tokens [B, steps].  At every step of
     every unfinished sequence the engine's token must be the oracle's argmax or lose to it by
     less than the near-tie allowance; finished sequences must continue with `pad`.  `scores` [B] (the engine's
-    summed log-probabilities) are compared with the oracle's sum over the engine's tokens.
+    summed log-probabilities) are compared with the oracle's sum over the engine's tokens;
+    `engine_logits` [B, steps, V] (the engine's processed scores, return_logits) with the oracle's
+    log-probabilities of the same step: the same entries at -inf, the others within twice the
+    near-tie allowance.
     Returns (steps where the token is exactly the oracle's argmax, steps checked)."""
     tokens = np.asarray(tokens)
     b, steps = tokens.shape
@@ -74,6 +77,11 @@ def check_greedy_steps(oracle, enc, prompt, tokens, eos, pad, logits_filter=None
             if length_temperature is not None:
                 z = z * float(lengths[i] + 1) ** length_temperature
             margin = row_margin(z)
+            if engine_logits is not None:
+                got, ref = np.asarray(engine_logits[i, t]), lp[i].numpy()
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (i, t)
+                live = ~np.isneginf(ref)
+                assert np.abs(got[live] - ref[live]).max() < 2 * margin, (i, t, np.abs(got[live] - ref[live]).max(), margin)
             best = int(lp[i].argmax())
             if best == tokens[i, t]:
                 exact += 1

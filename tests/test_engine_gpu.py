@@ -210,6 +210,33 @@ def test_timestamp_filter(small):
         assert not (ts[:-2] & ts[1:-1] & ts[2:]).any()      # never three timestamps in a row
 
 
+def test_return_logits(small):
+    """`return_logits` (generation_utils.py:266-268, 297): the processed scores of every greedy step,
+    with the timestamp rules on so that the filter's -inf entries are part of the comparison; and
+    the same tokens as the call without it (which replays a recorded graph instead)."""
+    from speech_to_text_amd.engine import TimestampFilter
+    dims, engine, oracle, mel = small
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    filt = TimestampFilter(remove_tokens=[10, 11, 12], remove_tokens_with_space=[10, 11, 12, 13, 900],
+                           timestamp_begin_idx=920, eos_token_idx=900)
+    kw = dict(max_new_tokens=10, eos_token=900, pad_token=900, early_stopping=False, logits_filter=filt)
+    tokens, lengths, scores, logits = engine.generate(prompt, return_logits=True, **kw)
+    assert logits.shape == (3, 10, dims.n_vocab) and logits.is_cuda
+    plain = engine.generate(prompt, **kw)
+    assert np.array_equal(plain[0], tokens) and np.allclose(plain[2], scores, atol=1e-5)
+    cfg = om.FilterConfig(remove_tokens=(10, 11, 12), remove_tokens_first=(10, 11, 12, 13, 900),
+                          timestamp_begin=920, eos=900)
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        P.check_greedy_steps(oracle, enc, prompt, tokens, 900, 900, logits_filter=cfg, scores=scores,
+                             engine_logits=logits.cpu().numpy())
+    picked = np.take_along_axis(logits.cpu().numpy(), tokens[:, :, None], axis=2)[:, :, 0]
+    assert np.allclose(picked.sum(axis=1), scores, atol=1e-3)           # scores = sum of the chosen entries
+    with pytest.raises(ValueError):
+        engine.generate(prompt, method="beam", num_beams=2, return_logits=True, **kw)
+
+
 def test_beam_search_with_timestamp_filter(small):
     """Beam search and the Whisper timestamp rules together (whisper.py:354-416 inside
     generation_utils.py:333-438), 5 beams: every transition against the oracle."""
