@@ -72,6 +72,28 @@ int64_t stt_logmel_static_max_samples(void);
 int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64_t n_samples,
                           float* d_mel, void* stream);
 
+/* ---- audio pre-steps on the device (what the reference's read_audio does on the host between
+ * reading a file and the mel, utils/audio/audio_io.py:249-264) ---- */
+#define STT_PCM_F32 0
+#define STT_PCM_I16 1
+
+/* Bytes of device workspace stt_pcm_normalize needs (8-byte aligned). */
+size_t stt_pcm_workspace_bytes(void);
+
+/* normalize_audio(audio, max_val = 1.) of utils/audio/audio_processing.py:48-60: d_out[i] =
+ * float32((d_in[i] - mean) * (1 / max|d_in - mean|)), the clip unchanged apart from the mean when
+ * it is flat (peak <= 1e-9).  d_in: n samples of `dtype` (STT_PCM_I16: what wavfile.read / ffmpeg
+ * s16le give; reduced and scaled in float64 as numpy does, result bit-identical to the host
+ * function.  STT_PCM_F32: float32 arithmetic as numpy's, the mean summed in float64). */
+int stt_pcm_normalize(const void* d_in, int dtype, int64_t n, float* d_out, void* d_workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Per-block peak of x^2 for the RMS silence trimming (utils/audio/audio_processing.py:120-127):
+ * d_peaks[b] = max over samples [b * block_size, (b + 1) * block_size) of d_pcm[i]^2 (float32
+ * product), b < ceil(n / block_size).  Which blocks are silent and what is cut is decided on the
+ * host from these ceil(n / block_size) values (:128-198). */
+int stt_pcm_block_peaks(const float* d_pcm, int64_t n, int block_size, float* d_peaks, void* stream);
+
 /* The two halves of stt_logmel_run, for a clip whose frames are computed in several
  * pieces (for instance on several GPUs) and share one clip-wide maximum:
  *  stage1 computes frames [frame_begin, frame_begin + frame_count) of a clip of

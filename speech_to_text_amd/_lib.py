@@ -34,6 +34,9 @@ def _declare(lib):
         "stt_logmel_run_static": (i32, [vp, vp, i64, vp, vp]),
         "stt_logmel_stage1": (i32, [vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, sz, vp]),
         "stt_logmel_stage2": (i32, [vp, vp, i64, vp, vp, vp]),
+        "stt_pcm_workspace_bytes": (sz, []),
+        "stt_pcm_normalize": (i32, [vp, i32, i64, vp, vp, sz, vp]),
+        "stt_pcm_block_peaks": (i32, [vp, i64, i32, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

@@ -165,6 +165,7 @@ class Whisper(object):
         else:
             self.mel_fn = WhisperSTFT(n_mel_channels=n_mels)
         self.trim_kwargs = dict(trim_silence=True, **WHISPER_TRIM_KWARGS)
+        self._device_audio = None
         self.model.set_tokens(sos_token=self.sos_token_idx, eos_token=self.eos_token_idx,
                               pad_token=self.eos_token_idx)
         t = list(self.vocabulary.non_speech_token_indexes) + list(self.vocabulary.special_token_indexes)
@@ -199,7 +200,16 @@ class Whisper(object):
                                self.timestamp_begin_idx, self.eos_token_idx)
 
     # ---- inputs
-    def get_audio(self, data, **kwargs):
+    def get_audio(self, data, device_pipeline=False, **kwargs):
+        """Normalised, silence-trimmed clip: a float32 numpy array from the host pre-steps (what the
+        reference runs, utils/audio/audio_io.py:249-264), or with `device_pipeline = True` a CUDA
+        tensor from the same steps run on the GPU (audio/device_pipeline.py: the clip crosses the
+        link once, as int16)."""
+        if device_pipeline:
+            if self._device_audio is None:
+                from ..audio.device_pipeline import DeviceAudioPipeline
+                self._device_audio = DeviceAudioPipeline(rate=self.rate)
+            return self._device_audio(data, **{**self.trim_kwargs, **kwargs})[1]
         _, audio = read_audio(data, rate=self.rate, **{**self.trim_kwargs, **kwargs})
         return audio
 
@@ -211,7 +221,8 @@ class Whisper(object):
             mel = torch.as_tensor(audio)
         else:
             keep = {k: v for k, v in kwargs.items() if k in ('normalize', 'trim_silence', 'mode', 'threshold',
-                                                            'min_silence', 'replace_by', 'min_voice_time')}
+                                                            'min_silence', 'replace_by', 'min_voice_time',
+                                                            'device_pipeline', 'rate')}
             mel = self.mel_fn(self.get_audio(audio, **keep))[0]
         return self.pad_or_trim(mel) if pad_or_trim else mel
 
