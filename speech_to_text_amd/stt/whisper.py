@@ -404,7 +404,7 @@ class Whisper(object):
         mel = self.get_input(audio, pad_or_trim=False, **kwargs)
         run_kwargs = {k: v for k, v in kwargs.items() if k not in
                       ('normalize', 'trim_silence', 'mode', 'threshold', 'min_silence', 'replace_by',
-                       'min_voice_time')}
+                       'min_voice_time', 'device_pipeline', 'rate')}
         if independent_windows:
             res = self.infer_windows(mel, **run_kwargs)
             segments = [res[w] for w in sorted(res)]
