@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--windows", type=int, default=1200, help="whisper: 30 s windows in the job (10 h)")
-    ap.add_argument("--batch", type=int, default=256, help="whisper: windows per engine call at most")
+    ap.add_argument("--batch", type=int, default=512, help="whisper: windows per engine call at most")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--logmel-steps", type=int, default=50, help="steps of the log-mel leg of the whisper line (0 = skip)")
     ap.add_argument("--pipelined", type=int, default=1, help="whisper: also measure two engines per GPU, one phase apart")
@@ -396,9 +396,12 @@ def bench_whisper(args, rank, world):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = whisper_cpu_baseline(args, dims, weights, mel[:1].cpu(), merged[mine[0]])
-    if args.pipelined and len(batches) >= 2:
+    # two engines have to fit the card: the pipelined leg runs calls of at most 256 windows
+    pb = min(per_call, 256)
+    pbatches = [mine[i: i + pb] for i in range(0, len(mine), pb)]
+    if args.pipelined and len(pbatches) >= 2:
         try:                                # every rank raises together (all_ranks_ok)
-            line["pipelined"] = bench_pipelined(args, dims, weights, eng, fn, run_batch, batches, world)
+            line["pipelined"] = bench_pipelined(args, dims, weights, eng, fn, run_batch, pbatches, world)
         except Exception as e:              # noqa: BLE001
             line["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del eng

@@ -206,11 +206,15 @@ GemmArgs gemm_args(const bf16_t* a, long lda, const bf16_t* w, const float* bias
 // resid != null: the product is added to the fp32 residual stream; for the skinny path that
 // happens later (the partial sums stay pending in e->slabs and are consumed by the next
 // add_layernorm), *pending_slabs returns how many.
+// Up to this many rows a layer goes through the decode-step kernels (weights streamed once, split-K
+// partial sums consumed by the next kernel); above it through the tiled large-M kernels.
+constexpr int kDecodeRows = 512;
+
 void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const float* bias, int rows,
            int n, int k, int epilogue, void* out, long ldc, int* pending_slabs, hipStream_t st) {
   GemmArgs g = gemm_args(a, lda, w, bias, out, ldc, rows, n, k, e->cfg.gelu_tanh);
   if (pending_slabs) *pending_slabs = 0;
-  if (rows <= 256) {
+  if (rows <= kDecodeRows) {
     if (epilogue == EPI_RESID_F32) {
       const int s = pick_split_k(rows, n, k, e->n_cu);
       launch_gemm_skinny(g, -1, s, e->slabs, st);
@@ -245,7 +249,7 @@ int alloc_buffers(stt_engine* e) {
   e->max_seq = e->max_batch * e->max_beams;
   e->max_rows = e->max_seq * e->max_prompt;
   const size_t S = e->max_seq, MR = e->max_rows, L = e->max_len;
-  const size_t slab_rows = MR < 256 ? MR : 256;
+  const size_t slab_rows = MR < kDecodeRows ? MR : kDecodeRows;
   if ((rc = buf_alloc(e, &e->dx, MR * d)) || (rc = buf_alloc(e, &e->dh, MR * d)) ||
       (rc = buf_alloc(e, &e->dqkv, MR * 3 * d)) || (rc = buf_alloc(e, &e->datt, MR * d)) ||
       (rc = buf_alloc(e, &e->dq, MR * d)) || (rc = buf_alloc(e, &e->df, MR * 4 * d)) ||
@@ -483,7 +487,7 @@ int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last
     // the blocks of an unsplit launch) and the attention kernel sums the slabs as it loads q
     CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[l], e->cross_v[l], e->datt,
                      n_seq / seq_per_win, seq_per_win, s_new, H, 1500};
-    if (rows <= 256) {
+    if (rows <= kDecodeRows) {
       GemmArgs gq = gemm_args(e->dh, d, L.wq_c, nullptr, nullptr, d, rows, d, d, e->cfg.gelu_tanh);
       const int sq = pick_split_k(rows, d, d, e->n_cu);
       launch_gemm_skinny(gq, -1, sq, e->slabs, st);
@@ -562,7 +566,7 @@ int stt_engine_probe_kernel(stt_engine* e, int kernel, int layer, void* stream_)
     const LayerW& L = e->dec[layer];
     CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[layer], e->cross_v[layer], e->datt,
                      rows, 1, 1, H, 1500};
-    if (rows <= 256) {
+    if (rows <= kDecodeRows) {
       ca.q_slabs = e->slabs; ca.n_q_slabs = pick_split_k(rows, d, d, e->n_cu);
       ca.q_slab_stride = (long)rows * d; ca.q_bias = L.bq_c;
     }
