@@ -68,6 +68,14 @@ class WhisperVocabulary(object):
         self.nospeech_token_idx = 50362
         self.notimestamps_idx = 50363
         self.timestamp_begin_idx = vocab_size
+        if vocab_size == 50365:
+            # the large-v3 tokenizer: one more language token (<|yue|>) in front of the task tokens
+            # moves every id after it up by one (n_vocab 51866 = 50365 + 1501 timestamps)
+            self.lang_to_idx['yue'] = 50358
+            self.idx_to_lang[50358] = 'yue'
+            self.translate_token_idx, self.transcribe_token_idx = 50359, 50360
+            self.start_of_lm_idx, self.start_of_prev_token_idx = 50361, 50362
+            self.nospeech_token_idx, self.notimestamps_idx = 50363, 50364
         names = getattr(tokenizer, 'index', None)
         if names and '<|endoftext|>' in names and '<|startoftranscript|>' in names:
             # ids from the file instead of the whisper-base constants (a large-v3 tokenizer has one
@@ -154,6 +162,11 @@ class Whisper(object):
             path = 'random:{}'.format(pretrained)
         self.model = build_runtime(runtime, path, max_batch=max_batch,
                                    **{k: v for k, v in kwargs.items() if k in ('gelu', 'reload')})
+        if vocabulary is None and self.model.dims['n_vocab'] == 51866:
+            # no tokenizer given and large-v3 weights: the ids of that checkpoint's own tokenizer
+            # rather than whisper-base's, which the reference always loads (utils/text/tokenizer.py:
+            # 870-872) and which is off by one from <|translate|> on for this model
+            self.vocabulary = WhisperVocabulary(vocab_size=50365)
         n_mels = self.model.dims['n_mels']
         mel_file = os.path.join(path, 'saving', 'mel_fn.json') if isinstance(path, str) else ''
         if os.path.isfile(mel_file):                  # written by the reference's MelSTFT.save (stft.py:164-182)

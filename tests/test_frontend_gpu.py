@@ -107,3 +107,36 @@ def test_one_hour_properties(stft_fns):
         mask = (got > floor + 1e-6) & (ref > floor + 1e-6)
         assert mask.mean() > 0.99
         assert np.abs(got - ref)[mask].max() < TOL
+
+
+def test_two_threads_two_streams(stft_fns):
+    """Two host threads, each on its own stream, calling one WhisperSTFT at the same time: plans
+    (ticket counter, per-block maxima) are per stream, so each gets the single-threaded result."""
+    import threading
+    import torch
+    fn = stft_fns[80]
+    rng = np.random.default_rng(8)
+    clips = [rng.uniform(-1, 1, 16000 * 50 + 17 * i).astype(np.float32) for i in range(2)]
+    for c in clips:
+        c[3000:40000] = 0.0                       # the clamp matters: the clip maximum must be this clip's
+    clips[1] *= 1e-3
+    want = [fn(c)[0].cpu().numpy() for c in clips]
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(20):
+                    out = fn(clips[i])[0]
+                got[i] = out.cpu().numpy()
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for i in range(2):
+        assert np.array_equal(got[i], want[i])

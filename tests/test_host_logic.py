@@ -146,3 +146,15 @@ def test_reference_callable_filter_is_translated():
     assert f.remove_tokens.tolist() == [7] and f.max_initial_timestamp == 0
     assert TimestampFilter.from_callable(lambda scores, **kw: scores) is None
     assert TimestampFilter.from_callable(functools.partial(logits_filter, object())) is None
+
+
+def test_large_v3_special_token_ids():
+    """The large-v3 tokenizer has one more language token than whisper-base's: every id from
+    <|translate|> on is one higher and the timestamps start at 50365 (n_vocab 51866)."""
+    from speech_to_text_amd.stt.whisper import WhisperVocabulary
+    base, v3 = WhisperVocabulary(), WhisperVocabulary(vocab_size=50365)
+    assert (base.translate_token_idx, base.transcribe_token_idx, base.timestamp_begin_idx) == (50358, 50359, 50364)
+    assert (v3.translate_token_idx, v3.transcribe_token_idx, v3.timestamp_begin_idx) == (50359, 50360, 50365)
+    assert v3.lang_to_idx["yue"] == 50358 and len(v3.lang_to_idx) == 100 and v3.lang_to_idx["en"] == 50259
+    assert v3.start_of_prev_token_idx == 50362 and v3.notimestamps_idx == 50364
+    assert v3.eos_token_idx == base.eos_token_idx == 50257 and v3.sos_token_idx == 50258
