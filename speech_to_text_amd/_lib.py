@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("STT_MI355X_LIB", os.path.join(_HERE, "libstt_mi355x.s
 
 _c = ctypes
 _lib = None
+ABI_VERSION = 3          # include/stt_mi355x.h: bumped on any signature or structure change
 
 
 class SttError(RuntimeError):
@@ -58,6 +59,10 @@ def load():
         import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
+        if lib.stt_abi_version() != ABI_VERSION:        # the ctypes structures here mirror one version
+            raise ImportError("%s has ABI version %d, this package binds version %d: rebuild it with "
+                              "`make -C %s`" % (LIB_PATH, lib.stt_abi_version(), ABI_VERSION,
+                                                os.path.join(_HERE, "csrc")))
         _lib = lib
     return _lib
 
