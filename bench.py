@@ -127,6 +127,26 @@ def all_ranks_ok(ok, world):
     return bool(ok)
 
 
+def measured_traffic(csv_name, kernel_prefix):
+    """HBM bytes per launch of one kernel from a committed `rocprofv3 --pmc` summary under profiles/
+    (FETCH_SIZE and WRITE_SIZE passes, corrected as the file's header says).  The counters cannot be
+    read from inside the process, so this is the figure of the profiled run, not of this one; None when
+    the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r2", csv_name)
+    if not os.path.exists(path):
+        return None
+    import csv
+    with open(path) as f:
+        rows = list(csv.DictReader(line for line in f if not line.startswith("#")))
+    total = 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        hit = [r for r in rows if r["kernel"].startswith(kernel_prefix) and r["counter"] == counter]
+        if not hit:
+            return None
+        total += int(hit[0]["bytes_corrected"])
+    return total
+
+
 def host_threads():
     return min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
 
@@ -183,9 +203,15 @@ def bench_logmel(args, rank, world, steps, warmup):
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "logmel_pair<%d>" % args.n_mels, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "traffic_note": "HBM bytes cannot be read from inside the process: see "
-                "the rocprofv3 --pmc passes under profiles/ (FETCH_SIZE / WRITE_SIZE) for this kernel",
+                "traffic": None, "traffic_note": "HBM bytes cannot be read from inside the process",
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+    if args.n_mels == 80 and abs(args.hours - 1.0) < 1e-9:
+        t = measured_traffic("logmel_1h_pmc_hbm.csv", "logmel_pair<80")
+        if t is not None:
+            roofline["traffic"] = t
+            roofline["traffic_note"] = ("bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                        "over this workload (profiles/r2/logmel_1h_pmc_hbm.csv); the counters cannot "
+                                        "be read from inside the process")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -351,6 +377,14 @@ def bench_whisper(args, rank, world):
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": k_bytes,
                 "windows_per_launch": n_b, "launches_per_step_and_rank": launches,
                 "share_of_step": round(launches * k_ms * 1e-3 / (dt / steps), 3)}
+    if dims["n_text_state"] == 1280 and dims["n_text_layer"] == 32:
+        t256 = measured_traffic("decode256_pmc_hbm.csv", "void attn_decoder_cross_kernel<1, 4>")
+        if t256 is not None:
+            roofline["traffic"] = int(round(t256 * n_b / 256.0))
+            roofline["traffic_note"] = ("separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured %d bytes per "
+                                        "256-window launch of this kernel (profiles/r2/decode256_pmc_hbm.csv; the "
+                                        "profiler does not survive the 512-window engine); scaled by windows per "
+                                        "launch / 256" % t256)
     step_bytes = token_step_bytes(dims, n_b)
     line = {
         "metric": "audio-sec transcribed/sec, whisper-%s greedy" % args.model,

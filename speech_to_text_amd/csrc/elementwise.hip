@@ -96,7 +96,17 @@ __global__ __launch_bounds__(256) void add_layernorm_row_kernel(
   const int nv = d >> 2;
   const long in_row = (long)row * row_mul + row_off;
   float* xr = x + in_row * d;
-  float4 v[2];
+  float4 v[2], gm[2], bt[2];
+  // Every load of the kernel is issued before the first wait: the row, its pending partial sums,
+  // the bias and the scale / shift vectors (needed last) all travel in one memory latency.
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      gm[i] = ((const float4*)gamma)[c];
+      bt[i] = ((const float4*)beta)[c];
+    }
+  }
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void add_layernorm_row_kernel(
   for (int i = 0; i < 2; ++i) {
     const int c = tid + 256 * i;
     if (c < nv) {
-      const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+      const float4 g = gm[i], b = bt[i];
       float4 o;
       o.x = (v[i].x - mean) * rstd * g.x + b.x;
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
