@@ -19,30 +19,30 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_t{a, b}, bf2_t));
 }
-// multiply eight packed bf16 by 1/8 (exact: a power of two)
-__device__ __forceinline__ uint4 scale8(uint4 v) {
-  uint32_t* p = (uint32_t*)&v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = __uint_as_float(p[i] << 16) * 0.125f, hi = __uint_as_float(p[i] & 0xFFFF0000u) * 0.125f;
-    p[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
-  }
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Encoder self-attention (no mask), flash style, one wave = 64 queries, 32 keys per step.
 // S^T = K Q^T with v_mfma_f32_32x32x16_bf16 puts a query on each lane (column) and 16 of the 32
 // keys in its registers (the other 16 in lane ^ 32), so the softmax statistics are per lane.
 // The S^T accumulator, rounded to bf16, is directly the B operand of O^T += V^T P^T, whose k
 // order inside a 16-key step is (register j of half h) -> key 16 s + 8 (j >> 2) + 4 h + (j & 3);
-// V^T is read from a [64][t_pad] image with that same order.
+// V^T is read from an image [head * 64 + feature][position of the whole batch] with that same order.
+//
+// q arrives scaled by log2(e) / 8 (the projection's epilogue does it in fp32, before the one
+// rounding to bf16), so scores are in base-2 units.  The softmax keeps a per-query reference r
+// instead of the exact running maximum m: r <= m <= r + 8.  The accumulator of the score product
+// starts at -r, so the matrix cores deliver s - r and a key costs one v_exp_f32, one add and half
+// a conversion; only when a tile raises some query's maximum more than 8 above its reference (or
+// on the first tile) does the wave take the branch that moves r and rescales that query's sums.
+// Weights are at most 2^8, at least one of them is >= 1, so fp32 sums neither overflow nor vanish.
+// Per tile the two 32-query halves are issued as QK(0), QK(1), softmax(0), PV(0), softmax(1),
+// PV(1): the matrix cores work on one half while the vector unit does the other's softmax.
 // ---------------------------------------------------------------------------------------------
 #define AE_K_BYTES (32 * 128)
 #define AE_TILE_BYTES (AE_K_BYTES + 64 * 72)
+#define AE_LIFT 8.0f
 __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
-    const bf16_t* __restrict__ vt, int t_pad, bf16_t* __restrict__ out, int t, int heads) {
+    const bf16_t* __restrict__ vt, long vt_pitch, bf16_t* __restrict__ out, int t, int heads) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
   const int d_model = heads * 64;
   const bf16_t* qb = q + b * batch_stride + h * 64;
   const bf16_t* kb = k + b * batch_stride + h * 64;
-  const bf16_t* vb = vt + ((long)b * heads + h) * 64 * t_pad;
+  const bf16_t* vb = vt + (long)h * 64 * vt_pitch + (long)b * t;   // 8-byte aligned: t % 4 == 0
 
   bf8_t qf[2][4];
 #pragma unroll
@@ -59,16 +59,19 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     int qi = q0 + 32 * x + c; qi = qi < t ? qi : t - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qf[x][s] = __builtin_bit_cast(bf8_t, scale8(*(const uint4*)(qb + (long)qi * ld + 16 * s + 8 * hh)));
+      qf[x][s] = __builtin_bit_cast(bf8_t, *(const uint4*)(qb + (long)qi * ld + 16 * s + 8 * hh));
   }
-  f16_t o[2][2];
+  f16_t o[2][2], nref[2];                          // nref = -r in all sixteen registers
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nref[x][r] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[x][dt][r] = 0.f;
-  float mrun[2] = {-__builtin_inff(), -__builtin_inff()}, lrun[2] = {0.f, 0.f};
+  }
+  float lsum[2] = {0.f, 0.f};                      // this lane's half of the row sum
 
   // The block's four waves walk the same keys, so a 32-key tile of K ([32][64], 128-byte rows,
   // 16-byte pieces XOR-swizzled by row) and of V^T ([64][32], rows padded to 72 bytes) is staged
@@ -79,17 +82,20 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
   const int v_row = tid >> 2, v_piece = tid & 3;          // V^T tile: 64 rows x 4 pieces
   const unsigned k_dst = k_row * 128 + ((k_piece ^ (k_row & 7)) << 4);
   const unsigned v_dst = AE_K_BYTES + v_row * 72 + v_piece * 16;
-  uint4 k_reg, v_reg;
+  uint4 k_reg;
+  uint2 v_reg[2];
   auto fetch = [&](int key0) {
     int ki = key0 + k_row; ki = ki < t ? ki : t - 1;
     k_reg = *(const uint4*)(kb + (long)ki * ld + 8 * k_piece);
-    v_reg = *(const uint4*)(vb + (long)v_row * t_pad + key0 + 8 * v_piece);
+    const bf16_t* vp = vb + (long)v_row * vt_pitch + key0 + 8 * v_piece;
+    v_reg[0] = *(const uint2*)vp;          // keys past t belong to the next window (or the
+    v_reg[1] = *(const uint2*)(vp + 4);    // padding): finite values under a weight of zero
   };
   auto stash = [&](int buf) {
     unsigned char* base = tile + buf * AE_TILE_BYTES;
     *(uint4*)(base + k_dst) = k_reg;
-    *(uint2*)(base + v_dst) = uint2{v_reg.x, v_reg.y};
-    *(uint2*)(base + v_dst + 8) = uint2{v_reg.z, v_reg.w};
+    *(uint2*)(base + v_dst) = v_reg[0];
+    *(uint2*)(base + v_dst + 8) = v_reg[1];
   };
   fetch(0);
   stash(0);
@@ -112,36 +118,47 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
         const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 16);
         vf[dt][s2] = __builtin_bit_cast(bf8_t, uint4{lo.x, lo.y, hi.x, hi.y});
       }
+    const bool first = it == 0, ragged = key0 + 32 > t;
+    f16_t sc[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-      f16_t s;
+      sc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[x][0], nref[x], 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int ss = 1; ss < 4; ++ss)
+        sc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ss], qf[x][ss], sc[x], 0, 0, 0);
+    }
 #pragma unroll
-      for (int ss = 0; ss < 4; ++ss)
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ss], qf[x][ss], s, 0, 0, 0);
-      if (key0 + 32 > t) {
+    for (int x = 0; x < 2; ++x) {
+      f16_t& s = sc[x];
+      if (ragged) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
           if (key >= t) s[r] = -__builtin_inff();
         }
       }
-      float mx = s[0];
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // softmax in base 2: exp(s - m) = 2^((s - m) log2 e), one v_exp_f32 per score
-      const float kLog2e = 1.4426950408889634f;
-      const float mnew = fmaxf(mrun[x], mx);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[x] - mnew) * kLog2e);
-      const float moff = mnew * kLog2e;
-      float rs = 0.f;
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      if (first || __builtin_amdgcn_ballot_w64(mx > AE_LIFT) != 0) {
+        // move the reference of the queries whose maximum ran away (all of them on the first tile)
+        const float mq = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float lift = (first || mq > AE_LIFT) ? mq : 0.f;
+        if (lift == -__builtin_inff()) lift = 0.f;
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-lift);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], kLog2e, -moff)); rs += s[r]; }
-      rs += __shfl_xor(rs, 32, 64);
-      lrun[x] = lrun[x] * alpha + rs;
-      mrun[x] = mnew;
+        for (int r = 0; r < 16; ++r) { s[r] -= lift; nref[x][r] -= lift; }
+        lsum[x] *= alpha;
+        o[x][0] *= alpha;
+        o[x][1] *= alpha;
+      }
+      f2_t part = f2_t{0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) part += f2_t{s[r], s[r + 1]};
+      lsum[x] += part[0] + part[1];
       bf8_t pf[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -150,15 +167,11 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
         u.z = pack2(s[8 * s2 + 4], s[8 * s2 + 5]); u.w = pack2(s[8 * s2 + 6], s[8 * s2 + 7]);
         pf[s2] = __builtin_bit_cast(bf8_t, u);
       }
-      // the running maximum settles after a few steps: rescale only when some lane's moved
-      const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        if (rescale) o[x][dt] *= alpha;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
           o[x][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][s2], pf[s2], o[x][dt], 0, 0, 0);
-      }
     }
     if (more) stash((it + 1) & 1);
     __syncthreads();
@@ -166,8 +179,9 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
     const int qi = q0 + 32 * x + c;
+    const float l = lsum[x] + __shfl_xor(lsum[x], 32, 64);
     if (qi >= t) continue;
-    const float inv = 1.0f / lrun[x];
+    const float inv = 1.0f / l;
     bf16_t* dst = out + ((long)b * t + qi) * d_model + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -182,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 }
 
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
-                         const bf16_t* vt, int t_pad, bf16_t* out, int batch, int t, int heads,
+                         const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
                          hipStream_t stream) {
   hipLaunchKernelGGL(attn_encoder_kernel, dim3((t + 255) / 256, heads, batch), dim3(256), 0, stream,
-                     q, k, ld, batch_stride, vt, t_pad, out, t, heads);
+                     q, k, ld, batch_stride, vt, vt_pitch, out, t, heads);
 }
 
 // ---------------------------------------------------------------------------------------------

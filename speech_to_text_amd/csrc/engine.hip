@@ -227,6 +227,10 @@ void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const floa
   }
 }
 
+// Row pitch of the encoder's V^T image [head * 64 + feature][row of the batch]: every row of the
+// image starts on a 128-byte boundary and ends with at least 64 elements of padding.
+long vt_pitch(const stt_engine* e) { return ((long)e->max_batch * 1500 + 64 + 63) / 64 * 64; }
+
 // Every buffer whose size depends on the capacity (max_batch, max_beams, max_len, max_prompt).
 int alloc_buffers(stt_engine* e) {
   const stt_model_config& c = e->cfg;
@@ -237,10 +241,12 @@ int alloc_buffers(stt_engine* e) {
   if ((rc = buf_alloc(e, &e->mel_pad, B * 3002 * c.n_mels + 4096)) ||
       (rc = buf_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = buf_alloc(e, &e->ex, R * d)) ||
       (rc = buf_alloc(e, &e->eh, R * d)) || (rc = buf_alloc(e, &e->eqkv, R * 3 * d)) ||
-      (rc = buf_alloc(e, &e->evt, B * H * 64 * 1536)) || (rc = buf_alloc(e, &e->eatt, R * d)) ||
+      (rc = buf_alloc(e, &e->evt, H * 64 * (size_t)vt_pitch(e))) || (rc = buf_alloc(e, &e->eatt, R * d)) ||
       (rc = buf_alloc(e, &e->ef, R * 4 * d)) || (rc = buf_alloc(e, &e->enc_out, R * d))) return rc;
   STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
   STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
+  // the padding of the V^T image is read by the attention kernel (under zero weights) and never written
+  STT_HIP_OR_FAIL(hipMemset(e->evt, 0, H * 64 * (size_t)vt_pitch(e) * sizeof(bf16_t)), (void)0);
   e->cross_k.resize(c.n_text_layer); e->cross_v.resize(c.n_text_layer);
   for (int l = 0; l < c.n_text_layer; ++l)
     if ((rc = buf_alloc(e, &e->cross_k[l], B * H * T * 64)) ||
@@ -429,9 +435,13 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
     const LayerW& L = e->enc[l];
     launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln1g, L.ln1b, e->eh, nullptr, rows, d,
                          1e-5f, 1, 0, st);
-    launch_gemm_big(gemm_args(e->eh, d, L.wqkv, L.bqkv, e->eqkv, 3 * d, rows, 3 * d, d, gt), EPI_BF16, st);
-    launch_transpose_v(e->eqkv + 2 * d, 3L * d, (long)T * 3 * d, batch, T, H, 1536, e->evt, st);
-    launch_attn_encoder(e->eqkv, e->eqkv + d, 3L * d, (long)T * 3 * d, e->evt, 1536, e->eatt, batch,
+    {   // q (scaled for the base-2 softmax) | k into eqkv, v transposed into evt
+      GemmArgs gq = gemm_args(e->eh, d, L.wqkv, L.bqkv, e->eqkv, 3 * d, rows, 3 * d, d, gt);
+      gq.out2 = e->evt; gq.vt_pitch = vt_pitch(e);
+      gq.q_scale = 0.125f * 1.4426950408889634f;
+      launch_gemm_big(gq, EPI_QKV_ENC, st);
+    }
+    launch_attn_encoder(e->eqkv, e->eqkv + d, 3L * d, (long)T * 3 * d, e->evt, vt_pitch(e), e->eatt, batch,
                         T, H, st);
     launch_gemm_big(gemm_args(e->eatt, d, L.wo, L.bo, e->ex, d, rows, d, d, gt), EPI_RESID_F32, st);
     launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln2g, L.ln2b, e->eh, nullptr, rows, d,

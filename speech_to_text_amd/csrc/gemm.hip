@@ -94,9 +94,19 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
         *(uint2*)(out + (((long)bi * (dm >> 6) + (nn >> 6)) * g.kv_t + t) * 64 + (nn & 63)) = p;
         continue;
       }
+      if (EPI == EPI_QKV_ENC) {                // a 4-group never straddles q | k | v or a head
+        const int dm = N / 3;
+        if (n < dm) v *= g.q_scale;
+        if (n >= 2 * dm) {
+          bf16_t* vt = (bf16_t*)g.out2 + (long)(n - 2 * dm) * g.vt_pitch + m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vt[(long)r * g.vt_pitch] = f2bf(v[r]);
+          continue;
+        }
+      }
       const long o = out_base + (long)m * g.ldc + n;
       const bool vec = nv == 4 && ((o & 3) == 0);
-      if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+      if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC) {
         bf16_t* out = (bf16_t*)g.out;
         if (vec) {
           uint2 p;
@@ -135,6 +145,40 @@ template <int EPI>
 __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
                                                    int nbase, int lane, unsigned char* stage) {
   const int fr = lane & 15, fg = lane >> 4;
+  if (EPI == EPI_QKV_ENC && nbase >= 2 * (g.n / 3)) {
+    // The wave's 64 columns are one head of V: its 128 x 64 tile is parked transposed, [column][128
+    // rows] in 256-byte lines whose 8-byte pieces are XOR-swizzled by the lane group, and leaves
+    // as whole 256-byte runs of 128 positions of one feature (the image is indexed by the GEMM's
+    // row, so a run starts on a 256-byte boundary).
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = nbase + tn * 16 + 4 * fg;
+      const f4_t bias = g.bias ? *(const f4_t*)(g.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tm = 0; tm < 8; ++tm) {
+        const f4_t v = acc[tn][tm] + bias;
+        const int row = tm * 16 + fr;
+        const unsigned in_line = ((((unsigned)row >> 2) ^ ((unsigned)fg << 2)) << 3) + (row & 3) * 2;
+        const uint32_t p01 = gb_pack2(v[0], v[1]), p23 = gb_pack2(v[2], v[3]);
+        const int col = tn * 16 + 4 * fg;
+        *(bf16_t*)(stage + (col + 0) * 256 + in_line) = (bf16_t)(p01 & 0xFFFFu);
+        *(bf16_t*)(stage + (col + 1) * 256 + in_line) = (bf16_t)(p01 >> 16);
+        *(bf16_t*)(stage + (col + 2) * 256 + in_line) = (bf16_t)(p23 & 0xFFFFu);
+        *(bf16_t*)(stage + (col + 3) * 256 + in_line) = (bf16_t)(p23 >> 16);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); the region is private to the wave
+    const int pc = lane & 31;
+    bf16_t* vt = (bf16_t*)g.out2 + (long)(nbase - 2 * (g.n / 3)) * g.vt_pitch + mbase + 4 * pc;
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int col = it * 2 + (lane >> 5);
+      const uint2 q = *(const uint2*)(stage + col * 256 + ((pc ^ (((col >> 2) & 3) << 2)) << 3));
+      *(uint2*)(vt + (long)col * g.vt_pitch) = q;
+    }
+    return;
+  }
+  const float scale = (EPI == EPI_QKV_ENC && nbase < g.n / 3) ? g.q_scale : 1.0f;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int n = nbase + tn * 16 + 4 * fg;
@@ -142,6 +186,7 @@ __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc
 #pragma unroll
     for (int tm = 0; tm < 8; ++tm) {
       f4_t v = acc[tn][tm] + bias;
+      if (EPI == EPI_QKV_ENC) v *= scale;
       if (EPI == EPI_GELU_BF16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
@@ -313,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int ti
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's reads of the stage are done
   }
-  if ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_KV_HEADS) && m0 + 256 <= M &&
+  if ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_KV_HEADS || EPI == EPI_QKV_ENC) && m0 + 256 <= M &&
       (g.ldc & 7) == 0 && ((blockIdx.z * g.out_batch_stride) & 7) == 0) {
     __syncthreads();                         // every wave is done with the operand stages
     wide_epilogue_bf16<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (128 * 128));
@@ -441,6 +486,7 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
       case EPI_RESID_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESID_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_POS_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       case EPI_KV_HEADS: hipLaunchKernelGGL(gemm_wide_kernel<EPI_KV_HEADS>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
+      case EPI_QKV_ENC: hipLaunchKernelGGL(gemm_wide_kernel<EPI_QKV_ENC>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
       default: hipLaunchKernelGGL(gemm_wide_kernel<EPI_F32>, grid, dim3(512), 0, stream, g, tiles_n, n_tiles); break;
     }
     return;
@@ -454,6 +500,7 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
     case EPI_RESID_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_RESID_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     case EPI_GELU_POS_F32: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_POS_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     case EPI_KV_HEADS: hipLaunchKernelGGL(gemm_big_kernel<EPI_KV_HEADS>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
+    case EPI_QKV_ENC: hipLaunchKernelGGL(gemm_big_kernel<EPI_QKV_ENC>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     default: hipLaunchKernelGGL(gemm_big_kernel<EPI_F32>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
   }
 }

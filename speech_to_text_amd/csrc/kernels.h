@@ -16,6 +16,9 @@ enum GemmEpilogue {
   EPI_F32 = 4,         // out_f32[m][n] = acc (+ bias if given)
   EPI_KV_HEADS = 5,    // bf16, head-major: row m = (b, t) with t < kv_t, column n < N/2 -> out[b][h][t][c],
                        // n >= N/2 -> out2[b][h][t][c] with h = (n mod N/2) / 64, c = n mod 64 (cross K | V)
+  EPI_QKV_ENC = 6,     // encoder q | k | v projection (N = 3 d): q columns scaled by q_scale before the
+                       // rounding to bf16, q and k to out[m][n]; v columns (n >= 2 d) transposed into
+                       // out2[n - 2 d][vt_pitch] at position m
 };
 
 struct GemmArgs {
@@ -34,6 +37,8 @@ struct GemmArgs {
   int gelu_tanh;       // 1 = tanh approximation (Keras default), 0 = exact erf
   void* out2;          // EPI_KV_HEADS: the V image
   int kv_t;            // EPI_KV_HEADS: rows per batch item (1500)
+  float q_scale;       // EPI_QKV_ENC
+  long vt_pitch;       // EPI_QKV_ENC: row pitch of the V^T image in elements (multiple of 64)
 };
 
 // Tiled MFMA GEMM for M >= a few hundred rows (encoder, prompt pass).
@@ -66,10 +71,11 @@ void launch_embed(const int* tokens, const int* positions, const bf16_t* emb, co
                   float* x, int rows, int d, int n_vocab, int n_ctx, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention
-// Encoder self-attention, no mask.  q,k: [b][t][h][64] with row stride ld (q pre-scaled by the
-// kernel, 1/8); vt: [b][h][64][t_pad]; out bf16 [b][t][h*64].
+// Encoder self-attention, no mask.  q,k: [b][t][h][64] with row stride ld, q already multiplied
+// by log2(e) / 8 (EPI_QKV_ENC); vt: [h * 64][vt_pitch] with window b's positions at b * t ..,
+// vt_pitch >= batch * t + 32 and every element finite; out bf16 [b][t][h*64].
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
-                         const bf16_t* vt, int t_pad, bf16_t* out, int batch, int t, int heads,
+                         const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
                          hipStream_t stream);
 
 struct SelfAttnArgs {

@@ -51,8 +51,8 @@ def check_greedy_steps(oracle, enc, prompt, tokens, eos, pad, logits_filter=None
     less than the near-tie allowance; finished sequences must continue with `pad`.  `scores` [B] (the engine's
     summed log-probabilities) are compared with the oracle's sum over the engine's tokens;
     `engine_logits` [B, steps, V] (the engine's processed scores, return_logits) with the oracle's
-    log-probabilities of the same step: the same entries at -inf, the others within twice the
-    near-tie allowance.
+    log-probabilities of the same step: the same entries at -inf, the others within the near-tie
+    allowance as an rms over the row and within three times that each.
     Returns (steps where the token is exactly the oracle's argmax, steps checked)."""
     tokens = np.asarray(tokens)
     b, steps = tokens.shape
@@ -81,7 +81,13 @@ def check_greedy_steps(oracle, enc, prompt, tokens, eos, pad, logits_filter=None
                 got, ref = np.asarray(engine_logits[i, t]), lp[i].numpy()
                 assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (i, t)
                 live = ~np.isneginf(ref)
-                assert np.abs(got[live] - ref[live]).max() < 2 * margin, (i, t, np.abs(got[live] - ref[live]).max(), margin)
+                # a log-probability is a logit minus the row's normaliser, each good to the stated
+                # 0.02 std: 0.04 std as an rms over the row (a shift of the normaliser moves every
+                # entry alike); the worst of ~1000 entries sits near 0.08 std on either side of any
+                # change of rounding order, so the bound on it is 0.12 std
+                err = np.abs(got[live] - ref[live])
+                assert np.sqrt((err ** 2).mean()) < margin, (i, t, np.sqrt((err ** 2).mean()), margin)
+                assert err.max() < 3 * margin, (i, t, err.max(), margin)
             best = int(lp[i].argmax())
             if best == tokens[i, t]:
                 exact += 1
