@@ -31,18 +31,19 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 // rounding to bf16), so scores are in base-2 units.  The softmax keeps a per-query reference r
 // instead of the exact running maximum m: r <= m <= r + 8.  The accumulator of the score product
 // starts at -r, so the matrix cores deliver s - r and a key costs one v_exp_f32, one add and half
-// a conversion; only when a tile raises some query's maximum more than 8 above its reference (or
-// on the first tile) does the wave take the branch that moves r and rescales that query's sums.
-// Weights are at most 2^8, at least one of them is >= 1, so fp32 sums neither overflow nor vanish.
+// a conversion; only when a tile raises some query's maximum more than lift_at (8) above its
+// reference (or on the first tile) does the wave take the branch that moves r and rescales that
+// query's sums.  Weights are at most 2^8, at least one of them is >= 1, so fp32 sums neither
+// overflow nor vanish.
 // Per tile the two 32-query halves are issued as QK(0), QK(1), softmax(0), PV(0), softmax(1),
 // PV(1): the matrix cores work on one half while the vector unit does the other's softmax.
 // ---------------------------------------------------------------------------------------------
 #define AE_K_BYTES (32 * 128)
 #define AE_TILE_BYTES (AE_K_BYTES + 64 * 72)
-#define AE_LIFT 8.0f
 __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
-    const bf16_t* __restrict__ vt, long vt_pitch, bf16_t* __restrict__ out, int t, int heads) {
+    const bf16_t* __restrict__ vt, long vt_pitch, bf16_t* __restrict__ out, int t, int heads,
+    float lift_at) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -141,10 +142,10 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 #pragma unroll
       for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
       mx = fmaxf(mx, s[15]);
-      if (first || __builtin_amdgcn_ballot_w64(mx > AE_LIFT) != 0) {
+      if (first || __builtin_amdgcn_ballot_w64(mx > lift_at) != 0) {
         // move the reference of the queries whose maximum ran away (all of them on the first tile)
         const float mq = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float lift = (first || mq > AE_LIFT) ? mq : 0.f;
+        float lift = (first || mq > lift_at) ? mq : 0.f;
         if (lift == -__builtin_inff()) lift = 0.f;
         const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-lift);
 #pragma unroll
@@ -197,9 +198,9 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
                          const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
-                         hipStream_t stream) {
+                         float lift_at, hipStream_t stream) {
   hipLaunchKernelGGL(attn_encoder_kernel, dim3((t + 255) / 256, heads, batch), dim3(256), 0, stream,
-                     q, k, ld, batch_stride, vt, vt_pitch, out, t, heads);
+                     q, k, ld, batch_stride, vt, vt_pitch, out, t, heads, lift_at);
 }
 
 // ---------------------------------------------------------------------------------------------

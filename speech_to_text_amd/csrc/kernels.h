@@ -73,10 +73,12 @@ void launch_embed(const int* tokens, const int* positions, const bf16_t* emb, co
 // ---------------------------------------------------------------- attention
 // Encoder self-attention, no mask.  q,k: [b][t][h][64] with row stride ld, q already multiplied
 // by log2(e) / 8 (EPI_QKV_ENC); vt: [h * 64][vt_pitch] with window b's positions at b * t ..,
-// vt_pitch >= batch * t + 32 and every element finite; out bf16 [b][t][h*64].
+// vt_pitch >= batch * t + 32 and every element finite; out bf16 [b][t][h*64].  lift_at: how far (in
+// base-2 units) a tile may raise a query's maximum above its softmax reference before the
+// reference is moved; 8 in production, anything in (0, 100] gives the same result up to rounding.
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
                          const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
-                         hipStream_t stream);
+                         float lift_at, hipStream_t stream);
 
 struct SelfAttnArgs {
   const bf16_t* qkv;   // [rows][3*d]: q | k | v of the new tokens; rows = n_seq * s_new

@@ -37,6 +37,30 @@ def test_encoder_states(small):
     assert np.abs(got - ref).max() < 0.05 * ref.std()
 
 
+def test_encoder_attention_reference_moves(small, monkeypatch):
+    """The encoder attention keeps a softmax reference per query that it moves only when a tile
+    of keys raises the maximum far enough above it (a branch that ordinary inputs take on a few
+    tiles only).  With the threshold lowered to 1/16 (STT_MI355X_ATTN_LIFT, read by every encoder
+    pass) nearly every tile takes that branch, and with it raised to 100 only the first one does:
+    all three settings must meet the encoder tolerance, and they differ from one another by no more
+    than each differs from the oracle (a moved reference rescales the bf16-rounded weights by a
+    factor that is not a power of two, so the roundings differ, nothing else)."""
+    dims, engine, oracle, mel = small
+    with torch.no_grad():
+        ref = oracle.encoder(mel).numpy()
+    outs = []
+    for lift in (None, "0.0625", "100"):
+        if lift is None:
+            monkeypatch.delenv("STT_MI355X_ATTN_LIFT", raising=False)
+        else:
+            monkeypatch.setenv("STT_MI355X_ATTN_LIFT", lift)
+        got = engine.encode(mel, return_output=True).cpu().numpy()
+        assert _rel_l2(got, ref) < 1e-2, lift
+        outs.append(got)
+    assert _rel_l2(outs[1], outs[0]) < 5e-3 and _rel_l2(outs[2], outs[0]) < 5e-3
+    assert not np.array_equal(outs[1], outs[0])       # the hook did change the path taken
+
+
 def test_short_window_is_zero_padded(small):
     dims, engine, oracle, mel = small
     short = mel[:1, :1234]
