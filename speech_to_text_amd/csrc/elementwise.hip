@@ -200,60 +200,6 @@ void launch_pack_mel(const float* mel, int batch, int frames, int n_mels, bf16_t
   hipLaunchKernelGGL(pack_mel_kernel, dim3(240, batch), dim3(256), 0, stream, mel, frames, n_mels, out);
 }
 
-// v[b][t][h][64] -> vt[b][h][64][t_pad] through a 64 x 64 LDS tile, 16 bytes per global access:
-// a thread loads 8 features of one time step, and stores 8 time steps of one feature.
-__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long ld,
-                                                          long batch_stride, int t, int heads,
-                                                          int t_pad, bf16_t* __restrict__ vt) {
-  __shared__ bf16_t tile[64][72];          // [time][feature], rows padded to 144 bytes
-  const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 64;
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (tid >> 3) + 32 * i, piece = tid & 7;
-    const int tt = t0 + r;
-    uint4 val = uint4{0u, 0u, 0u, 0u};
-    if (tt < t) val = *(const uint4*)(v + b * batch_stride + (long)tt * ld + h * 64 + piece * 8);
-    *(uint4*)&tile[r][piece * 8] = val;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = (tid >> 3) + 32 * i, piece = tid & 7;      // feature, 8 time steps
-    if (t0 + piece * 8 >= t_pad) continue;                   // t_pad is a multiple of 8
-    uint32_t w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      w[e] = (uint32_t)tile[piece * 8 + 2 * e][f] | ((uint32_t)tile[piece * 8 + 2 * e + 1][f] << 16);
-    *(uint4*)(vt + (((long)b * heads + h) * 64 + f) * t_pad + t0 + piece * 8) = uint4{w[0], w[1], w[2], w[3]};
-  }
-}
-void launch_transpose_v(const bf16_t* v, long ld, long batch_stride, int batch, int t, int heads,
-                        int t_pad, bf16_t* vt, hipStream_t stream) {
-  hipLaunchKernelGGL(transpose_v_kernel, dim3((t_pad + 63) / 64, heads, batch), dim3(256), 0,
-                     stream, v, ld, batch_stride, t, heads, t_pad, vt);
-}
-
-// [b][t][h][64] (row stride ld) -> [b][h][t][64]
-__global__ void split_heads_kernel(const bf16_t* __restrict__ src, long ld, long batch_stride,
-                                   int t, int heads, bf16_t* __restrict__ dst) {
-  const int b = blockIdx.y;
-  const long n16 = (long)t * heads * 8;      // 16-byte pieces per batch element
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
-    const int piece = (int)(i & 7);
-    const long th = i >> 3;
-    const int h = (int)(th % heads);
-    const long tt = th / heads;
-    const uint4 val = *(const uint4*)(src + b * batch_stride + tt * ld + h * 64 + piece * 8);
-    *(uint4*)(dst + (((long)b * heads + h) * t + tt) * 64 + piece * 8) = val;
-  }
-}
-void launch_split_heads(const bf16_t* src, long ld, long batch_stride, int batch, int t, int heads,
-                        bf16_t* dst, hipStream_t stream) {
-  hipLaunchKernelGGL(split_heads_kernel, dim3(512, batch), dim3(256), 0, stream, src, ld,
-                     batch_stride, t, heads, dst);
-}
-
 // token + learned position embedding, no scaling (text_transformer_arch.py:173-193).
 __global__ void embed_kernel(const int* __restrict__ tokens, const int* __restrict__ positions,
                              const bf16_t* __restrict__ emb, const float* __restrict__ pos_emb,

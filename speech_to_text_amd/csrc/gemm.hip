@@ -48,21 +48,33 @@ typedef float gb_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t gb_pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(gb_f2{a, b}, gb_bf2));
 }
-// tanh-form GELU with one exp2 and one reciprocal: 0.5 x (1 + tanh(u)) = x / (1 + 2^(-2 u log2 e))
-__device__ __forceinline__ float gelu_fast(float x, int tanh_form) {
-  if (tanh_form) {
-    const float t = x * (1.0f + 0.044715f * x * x) * (-2.0f * 0.7978845608028654f * 1.4426950408889634f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+// GELU of four values.  TANH: the tanh form on packed pairs (v_pk_mul / v_pk_fma / v_pk_add, one
+// exp2 and one reciprocal per value), straight-line code so that the values' dependence chains
+// interleave; otherwise the exact erf form.
+template <bool TANH>
+__device__ __forceinline__ f4_t gelu4(f4_t v) {
+  if (TANH) {
+    const float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c2 = c1 * 0.044715f;
+    const f4_t t = (v * v * c2 + c1) * v;
+    f4_t den;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) den[r] = __builtin_amdgcn_exp2f(t[r]);
+    den += 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) den[r] = __builtin_amdgcn_rcpf(den[r]);
+    return v * den;
   }
-  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.7071067811865476f));
+  return v;
 }
 
 // Epilogue of the tiled kernels: the lane holds C[m = mbase + 16 tm + fr][n = nbase + 16 tn + 4 fg + r].
 // Everything is done on 4-wide vectors (16-byte bias / position / residual accesses, 8-byte bf16
 // stores); a ragged last column group falls back to scalars.
-template <int EPI, int TM>
-__device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
-                                             int fr, int fg) {
+template <int EPI, int TM, bool TANH>
+__device__ __forceinline__ void big_epilogue_t(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
+                                               int fr, int fg) {
   const int M = g.m, N = g.n;
   const long out_base = (long)blockIdx.z * g.out_batch_stride;
 #pragma unroll
@@ -80,10 +92,7 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
       const int m = mbase + tm * 16 + fr;
       if (m >= M) continue;
       f4_t v = acc[tn][tm] + bias;
-      if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
-      }
+      if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) v = gelu4<TANH>(v);
       if (EPI == EPI_KV_HEADS) {               // N % 128 == 0: a 4-group never straddles a head
         const int dm = N >> 1, sel = n >= dm, nn = sel ? n - dm : n;
         const int bi = m / g.kv_t, t = m - bi * g.kv_t;
@@ -136,14 +145,24 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
   }
 }
 
+// the GELU form is chosen once per kernel, outside the loops over the lane's outputs
+template <int EPI, int TM>
+__device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
+                                             int fr, int fg) {
+  if ((EPI == EPI_GELU_BF16 || EPI == EPI_GELU_POS_F32) && !g.gelu_tanh)
+    big_epilogue_t<EPI, TM, false>(g, acc, mbase, nbase, fr, fg);
+  else
+    big_epilogue_t<EPI, TM, true>(g, acc, mbase, nbase, fr, fg);
+}
+
 // bf16 epilogue of the wide kernel through LDS: a lane's accumulators are 4 consecutive features
 // of one row, so direct stores are 8-byte pieces, 16 rows per instruction.  Each wave instead
 // parks its 128 x 64 bf16 tile in its own 16 KB of the (now idle) operand stages (16-byte pieces
 // XOR-swizzled by row) and writes it back out as whole 128-byte rows, 8 rows per instruction.  Only full
 // tiles take this path (the caller checks); `stage` is this wave's private region.
-template <int EPI>
-__device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
-                                                   int nbase, int lane, unsigned char* stage) {
+template <int EPI, bool TANH>
+__device__ __forceinline__ void wide_epilogue_bf16_t(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
+                                                     int nbase, int lane, unsigned char* stage) {
   const int fr = lane & 15, fg = lane >> 4;
   if (EPI == EPI_QKV_ENC && nbase >= 2 * (g.n / 3)) {
     // The wave's 64 columns are one head of V: its 128 x 64 tile is parked transposed, [column][128
@@ -187,10 +206,7 @@ __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc
     for (int tm = 0; tm < 8; ++tm) {
       f4_t v = acc[tn][tm] + bias;
       if (EPI == EPI_QKV_ENC) v *= scale;
-      if (EPI == EPI_GELU_BF16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], g.gelu_tanh);
-      }
+      if (EPI == EPI_GELU_BF16) v = gelu4<TANH>(v);
       uint2 p;
       p.x = gb_pack2(v[0], v[1]);
       p.y = gb_pack2(v[2], v[3]);
@@ -219,6 +235,13 @@ __device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc
     const uint4 q = *(const uint4*)(stage + row * 128 + ((piece ^ (row & 7)) << 4));
     *(uint4*)(out + (long)(mbase + row) * g.ldc + nbase + piece * 8) = q;
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ void wide_epilogue_bf16(const GemmArgs& g, f4_t (&acc)[4][8], int mbase,
+                                                   int nbase, int lane, unsigned char* stage) {
+  if (EPI == EPI_GELU_BF16 && !g.gelu_tanh) wide_epilogue_bf16_t<EPI, false>(g, acc, mbase, nbase, lane, stage);
+  else wide_epilogue_bf16_t<EPI, true>(g, acc, mbase, nbase, lane, stage);
 }
 
 // fp32 residual epilogue of the wide kernel, same idea: the wave's 128 x 64 tile goes through its

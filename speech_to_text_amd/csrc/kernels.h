@@ -63,9 +63,6 @@ void launch_add_layernorm(float* x, const float* slabs, int n_slabs, long slab_s
 // and rows >= frames zero (pad_or_trim with 0.0).
 void launch_pack_mel(const float* mel, int batch, int frames, int n_mels, bf16_t* out,
                      hipStream_t stream);
-// v[b][t][h][64] (row stride ld) -> vt[b][h][64][t_pad] (zero beyond t)
-void launch_transpose_v(const bf16_t* v, long ld, long batch_stride, int batch, int t, int heads,
-                        int t_pad, bf16_t* vt, hipStream_t stream);
 // x[row][d] = E[token[row]][d] + P[pos[row]][d]
 void launch_embed(const int* tokens, const int* positions, const bf16_t* emb, const float* pos_emb,
                   float* x, int rows, int d, int n_vocab, int n_ctx, hipStream_t stream);
@@ -105,9 +102,6 @@ struct CrossAttnArgs {
   int n_win, seq_per_win, s_new, heads, t_enc;
 };
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream);
-// k,v rows [b][t][h][64] (row stride ld, column offsets given by the pointers) -> [b][h][t][64]
-void launch_split_heads(const bf16_t* src, long ld, long batch_stride, int batch, int t, int heads,
-                        bf16_t* dst, hipStream_t stream);
 
 // ---------------------------------------------------------------- generation
 struct GenState {          // all device pointers; n_seq = batch * beams
