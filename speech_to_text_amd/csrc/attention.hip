@@ -43,12 +43,28 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
     const bf16_t* __restrict__ vt, long vt_pitch, bf16_t* __restrict__ out, int t, int heads,
-    float lift_at) {
+    int n_batch, int nx, float lift_at) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  // Blocks are dispatched to the XCDs round robin by their linear index.  The nx query blocks of
+  // one (window, head) read the same 384 KB of K and V^T: numbered so that they are consecutive
+  // blocks of ONE XCD, they fetch it from memory once and share it in that XCD's L2 (numbered
+  // naively they land on nx different XCDs and every one of them pulls its own copy).
+  int xb, pair;
+  {
+    const int n_pairs = heads * n_batch, L = blockIdx.x;
+    if ((n_pairs & 7) == 0) {
+      const int slot = L >> 3;
+      xb = slot % nx;
+      pair = (slot / nx) * 8 + (L & 7);
+    } else {
+      xb = L % nx;
+      pair = L / nx;
+    }
+  }
+  const int b = pair / heads, h = pair - b * heads;
   __shared__ __attribute__((aligned(16))) unsigned char tile[2 * AE_TILE_BYTES];
-  const int q0 = blockIdx.x * 256 + wave * 64;     // waves past the end still help stage the tiles
+  const int q0 = xb * 256 + wave * 64;             // waves past the end still help stage the tiles
   const int d_model = heads * 64;
   const bf16_t* qb = q + b * batch_stride + h * 64;
   const bf16_t* kb = k + b * batch_stride + h * 64;
@@ -75,13 +91,15 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
   float lsum[2] = {0.f, 0.f};                      // this lane's half of the row sum
 
   // The block's four waves walk the same keys, so a 32-key tile of K ([32][64], 128-byte rows,
-  // 16-byte pieces XOR-swizzled by row) and of V^T ([64][32], rows padded to 72 bytes) is staged
+  // 16-byte pieces XOR-swizzled by (row / 2) % 8: two rows fill the 256-byte bank row, and the rows
+  // of one parity inside a 16-lane group of ds_read_b128 - lanes 0-3, 12-15, 20-27 and so on - then
+  // sit on eight different pieces) and of V^T ([64][32], rows padded to 72 bytes) is staged
   // once per block in LDS (two buffers; the next tile's global loads are in flight during the
   // MFMAs) instead of once per wave from L2.
   const int tid = threadIdx.x;
   const int k_row = tid >> 3, k_piece = tid & 7;          // K tile: 32 rows x 8 pieces
   const int v_row = tid >> 2, v_piece = tid & 3;          // V^T tile: 64 rows x 4 pieces
-  const unsigned k_dst = k_row * 128 + ((k_piece ^ (k_row & 7)) << 4);
+  const unsigned k_dst = k_row * 128 + ((k_piece ^ ((k_row >> 1) & 7)) << 4);
   const unsigned v_dst = AE_K_BYTES + v_row * 72 + v_piece * 16;
   uint4 k_reg;
   uint2 v_reg[2];
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     bf8_t kf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      kf[s] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + c * 128 + (((2 * s + hh) ^ (c & 7)) << 4)));
+      kf[s] = __builtin_bit_cast(bf8_t, *(const uint4*)(cur + c * 128 + (((2 * s + hh) ^ ((c >> 1) & 7)) << 4)));
     bf8_t vf[2][2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -154,12 +172,13 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
         o[x][0] *= alpha;
         o[x][1] *= alpha;
       }
-      f2_t part = f2_t{0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+      // plain adds in two chains: beside MFMAs a packed add costs more issue time than two scalar ones
+      float pa = s[0], pb = s[1];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) part += f2_t{s[r], s[r + 1]};
-      lsum[x] += part[0] + part[1];
+      for (int r = 2; r < 16; r += 2) { pa += s[r]; pb += s[r + 1]; }
+      lsum[x] += pa + pb;
       bf8_t pf[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -199,8 +218,9 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
                          const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
                          float lift_at, hipStream_t stream) {
-  hipLaunchKernelGGL(attn_encoder_kernel, dim3((t + 255) / 256, heads, batch), dim3(256), 0, stream,
-                     q, k, ld, batch_stride, vt, vt_pitch, out, t, heads, lift_at);
+  const int nx = (t + 255) / 256;
+  hipLaunchKernelGGL(attn_encoder_kernel, dim3(nx * heads * batch), dim3(256), 0, stream,
+                     q, k, ld, batch_stride, vt, vt_pitch, out, t, heads, batch, nx, lift_at);
 }
 
 // ---------------------------------------------------------------------------------------------
