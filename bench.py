@@ -34,13 +34,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16
 PROMPT = [50258, 50259, 50359]
+# The chip needs about 20 ms of sustained work before a 0.14 ms kernel runs at its steady rate
+# (scripts/time_frontend_sustained.py: 151 us per 1 h call over the first 20 calls, 133.5 us from
+# the 400th on), so the log-mel legs warm up for this many steps before they time anything.
+LOGMEL_WARMUP = 400
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 2 (whisper) / 50 (logmel)")
-    ap.add_argument("--warmup", type=int, default=None, help="default: 1 (whisper) / 5 (logmel)")
+    ap.add_argument("--steps", type=int, default=None, help="default: 2 (whisper) / 200 (logmel)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 1 (whisper) / 400 (logmel)")
     ap.add_argument("--workload", default="whisper", choices=("whisper", "logmel"))
     ap.add_argument("--hours", type=float, default=1.0, help="logmel: audio hours per rank and step")
     ap.add_argument("--n-mels", type=int, default=80)
@@ -49,15 +53,15 @@ def parse():
     ap.add_argument("--windows", type=int, default=1200, help="whisper: 30 s windows in the job (10 h)")
     ap.add_argument("--batch", type=int, default=512, help="whisper: windows per engine call at most")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--logmel-steps", type=int, default=50, help="steps of the log-mel leg of the whisper line (0 = skip)")
+    ap.add_argument("--logmel-steps", type=int, default=200, help="steps of the log-mel leg of the whisper line (0 = skip)")
     ap.add_argument("--pipelined", type=int, default=1, help="whisper: also measure two engines per GPU, one phase apart")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 2 if a.workload == "whisper" else 50
+        a.steps = 2 if a.workload == "whisper" else 200
     if a.warmup is None:
-        a.warmup = 1 if a.workload == "whisper" else 5
+        a.warmup = 1 if a.workload == "whisper" else LOGMEL_WARMUP
     return a
 
 
@@ -544,7 +548,7 @@ def main():
         if args.logmel_steps > 0:
             # the extra leg must never cost the headline line: report its failure instead
             try:
-                line["logmel"] = bench_logmel(args, rank, world, args.logmel_steps, 5)
+                line["logmel"] = bench_logmel(args, rank, world, args.logmel_steps, LOGMEL_WARMUP)
             except Exception as e:          # noqa: BLE001  (every rank raises together: all_ranks_ok)
                 line["logmel"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
