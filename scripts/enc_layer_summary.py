@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first = [i for i, r in enumerate(rows) if "pack_mel" in r["Kernel_Name"]][-1]
 seq = [(r["Kernel_Name"][:44], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows[first:]]
 print("last pass: %d kernels, %.1f ms of kernel time" % (len(seq), sum(d for _, d in seq) / 1e3))
-marks = [i for i, s in enumerate(seq) if s[0].startswith("attn_encoder")]
+marks = [i for i, s in enumerate(seq) if "attn_encoder" in s[0]]
 agg = collections.defaultdict(list)
 for a, b in zip(marks[:-1], marks[1:]):
     for j, (name, d) in enumerate(seq[a:b]):
