@@ -57,6 +57,7 @@ struct stt_engine {
   bf16_t *mel_pad = nullptr, *h1_pad = nullptr, *eh = nullptr, *eqkv = nullptr, *evt = nullptr,
          *eatt = nullptr, *ef = nullptr, *enc_out = nullptr;
   float* ex = nullptr;
+  float* eslabs = nullptr;  // split-K partial sums of the encoder's residual projections (a few windows only)
   std::vector<bf16_t*> cross_k, cross_v;
   int enc_batch = 0;       // windows held by the last stt_encode
 
@@ -231,6 +232,21 @@ void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const floa
 // image starts on a 128-byte boundary and ends with at least 64 elements of padding.
 long vt_pitch(const stt_engine* e) { return ((long)e->max_batch * 1500 + 64 + 63) / 64 * 64; }
 
+// Encoder residual projections (N = d: 10 column tiles at large-v3) of a few windows leave most of
+// the chip idle - one window is 6 x 10 = 60 tiles of 256 x 128 for 256 CUs - so up to
+// kEncSplitWindows windows they split K over 4 blocks per tile; the partial sums go to slabs that
+// the following LayerNorm adds up with the bias and the residual (as the decode steps do).  The
+// split does not depend on the number of windows below that limit, so a window's result does not
+// depend on how many others (up to the limit) were encoded with it.  1 = no split.
+constexpr int kEncSplitWindows = 3;      // measured: 12.2 -> 8.7 ms at one window, 11.6 -> 9.4 at two, even at three, slower from four
+constexpr int kEncSplit = 4;
+int enc_split(const stt_engine* e, int batch, int k) {
+  static const int forced = getenv("STT_MI355X_ENC_SPLIT") ? atoi(getenv("STT_MI355X_ENC_SPLIT")) : 0;
+  const int s = forced > 0 ? forced : kEncSplit;
+  if (batch > kEncSplitWindows || s < 2 || s > kEncSplit || (k / 64) % s) return 1;
+  return s;
+}
+
 // Every buffer whose size depends on the capacity (max_batch, max_beams, max_len, max_prompt).
 int alloc_buffers(stt_engine* e) {
   const stt_model_config& c = e->cfg;
@@ -242,7 +258,8 @@ int alloc_buffers(stt_engine* e) {
       (rc = buf_alloc(e, &e->h1_pad, B * 3002 * d + 4096)) || (rc = buf_alloc(e, &e->ex, R * d)) ||
       (rc = buf_alloc(e, &e->eh, R * d)) || (rc = buf_alloc(e, &e->eqkv, R * 3 * d)) ||
       (rc = buf_alloc(e, &e->evt, H * 64 * (size_t)vt_pitch(e))) || (rc = buf_alloc(e, &e->eatt, R * d)) ||
-      (rc = buf_alloc(e, &e->ef, R * 4 * d)) || (rc = buf_alloc(e, &e->enc_out, R * d))) return rc;
+      (rc = buf_alloc(e, &e->ef, R * 4 * d)) || (rc = buf_alloc(e, &e->enc_out, R * d)) ||
+      (rc = buf_alloc(e, &e->eslabs, (size_t)kEncSplit * (B < kEncSplitWindows ? B : kEncSplitWindows) * T * d))) return rc;
   STT_HIP_OR_FAIL(hipMemset(e->mel_pad, 0, (B * 3002 * c.n_mels + 4096) * sizeof(bf16_t)), (void)0);
   STT_HIP_OR_FAIL(hipMemset(e->h1_pad, 0, (B * 3002 * d + 4096) * sizeof(bf16_t)), (void)0);
   // the padding of the V^T image is read by the attention kernel (under zero weights) and never written
@@ -404,6 +421,29 @@ int stt_engine_reserve(stt_engine* e, int max_batch, int max_beams, int max_text
   return alloc_buffers(e);
 }
 
+}  // extern "C"
+
+namespace {
+// ex += a @ w^T + bias for the encoder.  Returns 0 when the sum is already in ex, or the number of
+// split-K slabs in e->eslabs that the next LayerNorm has to add (with the bias).
+int residual_projection(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const float* bias, int rows,
+                        int batch, int k, hipStream_t st) {
+  const int d = e->cfg.n_audio_state;
+  const int s = enc_split(e, batch, k);
+  if (s == 1) {
+    launch_gemm_big(gemm_args(a, lda, w, bias, e->ex, d, rows, d, k, e->cfg.gelu_tanh), EPI_RESID_F32, st);
+    return 0;
+  }
+  GemmArgs g = gemm_args(a, lda, w, nullptr, e->eslabs, d, rows, d, k, e->cfg.gelu_tanh);
+  g.k_split = s;
+  g.split_stride = (long)rows * d;
+  launch_gemm_big(g, EPI_F32, st);
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
 // ------------------------------------------------------------------------------ encoder
 int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* d_enc_out,
                void* stream_) {
@@ -439,10 +479,13 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
     g.pos = e->enc_pos; g.pos_ld = d;
     launch_gemm_big(g, EPI_GELU_POS_F32, st);
   }
+  int pend = 0;                              // slabs of the last residual projection not yet added to ex
+  const float* pend_bias = nullptr;
+  const long slab_stride = (long)rows * d;
   for (int l = 0; l < c.n_audio_layer; ++l) {
     const LayerW& L = e->enc[l];
-    launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln1g, L.ln1b, e->eh, nullptr, rows, d,
-                         1e-5f, 1, 0, st);
+    launch_add_layernorm(e->ex, e->eslabs, pend, slab_stride, pend ? pend_bias : nullptr, L.ln1g, L.ln1b, e->eh,
+                         nullptr, rows, d, 1e-5f, 1, 0, st);
     {   // q (scaled for the base-2 softmax) | k into eqkv, v transposed into evt
       GemmArgs gq = gemm_args(e->eh, d, L.wqkv, L.bqkv, e->eqkv, 3 * d, rows, 3 * d, d, gt);
       gq.out2 = e->evt; gq.vt_pitch = vt_pitch(e);
@@ -451,14 +494,16 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
     }
     launch_attn_encoder(e->eqkv, e->eqkv + d, 3L * d, (long)T * 3 * d, e->evt, vt_pitch(e), e->eatt, batch,
                         T, H, lift_at, st);
-    launch_gemm_big(gemm_args(e->eatt, d, L.wo, L.bo, e->ex, d, rows, d, d, gt), EPI_RESID_F32, st);
-    launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, L.ln2g, L.ln2b, e->eh, nullptr, rows, d,
-                         1e-5f, 1, 0, st);
+    pend = residual_projection(e, e->eatt, d, L.wo, L.bo, rows, batch, d, st);
+    pend_bias = L.bo;
+    launch_add_layernorm(e->ex, e->eslabs, pend, slab_stride, pend ? pend_bias : nullptr, L.ln2g, L.ln2b, e->eh,
+                         nullptr, rows, d, 1e-5f, 1, 0, st);
     launch_gemm_big(gemm_args(e->eh, d, L.w1, L.b1, e->ef, 4 * d, rows, 4 * d, d, gt), EPI_GELU_BF16, st);
-    launch_gemm_big(gemm_args(e->ef, 4 * d, L.w2, L.b2, e->ex, d, rows, d, 4 * d, gt), EPI_RESID_F32, st);
+    pend = residual_projection(e, e->ef, 4 * d, L.w2, L.b2, rows, batch, 4 * d, st);
+    pend_bias = L.b2;
   }
-  launch_add_layernorm(e->ex, nullptr, 0, 0, nullptr, e->enc_lng, e->enc_lnb, e->enc_out, d_enc_out,
-                       rows, d, 1e-5f, 1, 0, st);
+  launch_add_layernorm(e->ex, e->eslabs, pend, slab_stride, pend ? pend_bias : nullptr, e->enc_lng, e->enc_lnb,
+                       e->enc_out, d_enc_out, rows, d, 1e-5f, 1, 0, st);
   // cross-attention K/V of every decoder layer, once per window
   for (int l = 0; l < c.n_text_layer; ++l) {
     const LayerW& L = e->dec[l];

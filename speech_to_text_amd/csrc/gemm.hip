@@ -76,7 +76,7 @@ template <int EPI, int TM, bool TANH>
 __device__ __forceinline__ void big_epilogue_t(const GemmArgs& g, f4_t (&acc)[4][TM], int mbase, int nbase,
                                                int fr, int fg) {
   const int M = g.m, N = g.n;
-  const long out_base = (long)blockIdx.z * g.out_batch_stride;
+  const long out_base = (long)blockIdx.z * g.out_batch_stride + (long)blockIdx.y * g.split_stride;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int n = nbase + tn * 16 + 4 * fg;
@@ -155,6 +155,44 @@ __device__ __forceinline__ void big_epilogue(const GemmArgs& g, f4_t (&acc)[4][T
     big_epilogue_t<EPI, TM, true>(g, acc, mbase, nbase, fr, fg);
 }
 
+// V tile of the encoder's q | k | v projection (EPI_QKV_ENC): the wave's 64 columns are one head
+// of V.  Its 128 x 64 tile is parked transposed in the wave's private 16 KB of LDS, [column][128
+// rows] in 256-byte lines whose 8-byte pieces are XOR-swizzled by the lane group, and leaves as
+// 8-byte pieces of whole 256-byte runs of 128 positions of one feature (the image is indexed by the
+// GEMM's row, so a run starts on a 256-byte boundary).  rows_valid (a multiple of 4) cuts the
+// tile at the end of the matrix.
+__device__ __forceinline__ void qkv_v_tile_store(const GemmArgs& g, f4_t (&acc)[4][8], int mbase, int nbase,
+                                                 int lane, unsigned char* stage, int rows_valid) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = nbase + tn * 16 + 4 * fg;
+    const f4_t bias = g.bias ? *(const f4_t*)(g.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      const f4_t v = acc[tn][tm] + bias;
+      const int row = tm * 16 + fr;
+      const unsigned in_line = ((((unsigned)row >> 2) ^ ((unsigned)fg << 2)) << 3) + (row & 3) * 2;
+      const uint32_t p01 = gb_pack2(v[0], v[1]), p23 = gb_pack2(v[2], v[3]);
+      const int col = tn * 16 + 4 * fg;
+      *(bf16_t*)(stage + (col + 0) * 256 + in_line) = (bf16_t)(p01 & 0xFFFFu);
+      *(bf16_t*)(stage + (col + 1) * 256 + in_line) = (bf16_t)(p01 >> 16);
+      *(bf16_t*)(stage + (col + 2) * 256 + in_line) = (bf16_t)(p23 & 0xFFFFu);
+      *(bf16_t*)(stage + (col + 3) * 256 + in_line) = (bf16_t)(p23 >> 16);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); the region is private to the wave
+  const int pc = lane & 31;
+  if (4 * pc >= rows_valid) return;
+  bf16_t* vt = (bf16_t*)g.out2 + (long)(nbase - 2 * (g.n / 3)) * g.vt_pitch + mbase + 4 * pc;
+#pragma unroll
+  for (int it = 0; it < 32; ++it) {
+    const int col = it * 2 + (lane >> 5);
+    const uint2 q = *(const uint2*)(stage + col * 256 + ((pc ^ (((col >> 2) & 3) << 2)) << 3));
+    *(uint2*)(vt + (long)col * g.vt_pitch) = q;
+  }
+}
+
 // bf16 epilogue of the wide kernel through LDS: a lane's accumulators are 4 consecutive features
 // of one row, so direct stores are 8-byte pieces, 16 rows per instruction.  Each wave instead
 // parks its 128 x 64 bf16 tile in its own 16 KB of the (now idle) operand stages (16-byte pieces
@@ -165,36 +203,7 @@ __device__ __forceinline__ void wide_epilogue_bf16_t(const GemmArgs& g, f4_t (&a
                                                      int nbase, int lane, unsigned char* stage) {
   const int fr = lane & 15, fg = lane >> 4;
   if (EPI == EPI_QKV_ENC && nbase >= 2 * (g.n / 3)) {
-    // The wave's 64 columns are one head of V: its 128 x 64 tile is parked transposed, [column][128
-    // rows] in 256-byte lines whose 8-byte pieces are XOR-swizzled by the lane group, and leaves
-    // as whole 256-byte runs of 128 positions of one feature (the image is indexed by the GEMM's
-    // row, so a run starts on a 256-byte boundary).
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = nbase + tn * 16 + 4 * fg;
-      const f4_t bias = g.bias ? *(const f4_t*)(g.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tm = 0; tm < 8; ++tm) {
-        const f4_t v = acc[tn][tm] + bias;
-        const int row = tm * 16 + fr;
-        const unsigned in_line = ((((unsigned)row >> 2) ^ ((unsigned)fg << 2)) << 3) + (row & 3) * 2;
-        const uint32_t p01 = gb_pack2(v[0], v[1]), p23 = gb_pack2(v[2], v[3]);
-        const int col = tn * 16 + 4 * fg;
-        *(bf16_t*)(stage + (col + 0) * 256 + in_line) = (bf16_t)(p01 & 0xFFFFu);
-        *(bf16_t*)(stage + (col + 1) * 256 + in_line) = (bf16_t)(p01 >> 16);
-        *(bf16_t*)(stage + (col + 2) * 256 + in_line) = (bf16_t)(p23 & 0xFFFFu);
-        *(bf16_t*)(stage + (col + 3) * 256 + in_line) = (bf16_t)(p23 >> 16);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); the region is private to the wave
-    const int pc = lane & 31;
-    bf16_t* vt = (bf16_t*)g.out2 + (long)(nbase - 2 * (g.n / 3)) * g.vt_pitch + mbase + 4 * pc;
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int col = it * 2 + (lane >> 5);
-      const uint2 q = *(const uint2*)(stage + col * 256 + ((pc ^ (((col >> 2) & 3) << 2)) << 3));
-      *(uint2*)(vt + (long)col * g.vt_pitch) = q;
-    }
+    qkv_v_tile_store(g, acc, mbase, nbase, lane, stage, 128);
     return;
   }
   const float scale = (EPI == EPI_QKV_ENC && nbase < g.n / 3) ? g.q_scale : 1.0f;
@@ -416,7 +425,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const GemmArgs g, int ti
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int tiles_n, int n_tiles) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[(GB_BM + GB_BN) * GB_BK * 2];
+  // operand stage (48 KB); the q | k | v projection parks its V tiles here afterwards (16 KB per wave)
+  constexpr int kSmem = (EPI == EPI_QKV_ENC && GB_TM == 8 && 4 * 16384 > (GB_BM + GB_BN) * GB_BK * 2)
+                            ? 4 * 16384 : (GB_BM + GB_BN) * GB_BK * 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[kSmem];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -432,7 +444,9 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
   const bf16_t* __restrict__ A = g.a + (long)blockIdx.z * g.a_batch_stride;
   const bf16_t* __restrict__ W = g.w;
   const int M = g.m, N = g.n, K = g.k;
-  const int nk = K / GB_BK;
+  const int kper = g.k_split > 1 ? K / g.k_split : K;      // this block's K slice (split-K over blockIdx.y)
+  const int kbeg = blockIdx.y * kper;
+  const int nk = kper / GB_BK;
   constexpr int kBOff = GB_BM * GB_BK * 2;
 
   // this lane's source rows of A and of W (DMA instruction j = wave + 4 i covers rows 8j..8j+7)
@@ -444,13 +458,13 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
   for (int i = 0; i < kADma; ++i) {
     const int row = 8 * (wave + 4 * i) + (lane >> 3);
     int gm = m0 + row; gm = gm < M ? gm : M - 1;
-    a_src[i] = A + (long)gm * g.lda + piece * 8;
+    a_src[i] = A + (long)gm * g.lda + kbeg + piece * 8;
   }
 #pragma unroll
   for (int i = 0; i < kWDma; ++i) {
     const int row = 8 * (wave + 4 * i) + (lane >> 3);
     int gn = n0 + row; gn = gn < N ? gn : N - 1;
-    w_src[i] = W + (long)gn * K + piece * 8;
+    w_src[i] = W + (long)gn * K + kbeg + piece * 8;
   }
 
   f4_t acc[4][GB_TM];   // [tn][tm]
@@ -494,12 +508,21 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g, int 
     __syncthreads();                        // everyone is done reading before the next fill
   }
 
+  if constexpr (EPI == EPI_QKV_ENC && GB_TM == 8) {
+    const int mbase = m0 + wm * (GB_BM / 2), nbase = n0 + wn * 64;
+    if (nbase >= 2 * (N / 3) && nbase + 64 <= N) {          // the last barrier of the loop freed the stage
+      const int left = M - mbase;
+      if (left > 0) qkv_v_tile_store(g, acc, mbase, nbase, lane, smem + wave * 16384, left < 128 ? left : 128);
+      return;
+    }
+  }
   big_epilogue<EPI, GB_TM>(g, acc, m0 + wm * (GB_BM / 2), n0 + wn * 64, fr, fg);
 }
 
 void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
   static const bool no_wide = getenv("STT_MI355X_NO_WIDE") != nullptr;
-  if (!no_wide && g.n % 256 == 0 && g.m >= 2048) {
+  const int ksplit = g.k_split > 1 ? g.k_split : 1;
+  if (!no_wide && ksplit == 1 && g.n % 256 == 0 && g.m >= 2048) {
     const int tiles_n = g.n / 256, tiles_m = (g.m + 255) / 256;
     const int n_tiles = tiles_n * tiles_m;
     dim3 grid(n_tiles, 1, g.batch > 0 ? g.batch : 1);
@@ -516,7 +539,7 @@ void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream) {
   }
   const int tiles_n = (g.n + GB_BN - 1) / GB_BN, tiles_m = (g.m + GB_BM - 1) / GB_BM;
   const int n_tiles = tiles_n * tiles_m;
-  dim3 grid(n_tiles, 1, g.batch > 0 ? g.batch : 1);
+  dim3 grid(n_tiles, ksplit, g.batch > 0 ? g.batch : 1);
   switch (epilogue) {
     case EPI_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_BF16>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;
     case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_big_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, stream, g, tiles_n, n_tiles); break;

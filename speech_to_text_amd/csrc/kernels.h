@@ -37,6 +37,8 @@ struct GemmArgs {
   int gelu_tanh;       // 1 = tanh approximation (Keras default), 0 = exact erf
   void* out2;          // EPI_KV_HEADS: the V image
   int kv_t;            // EPI_KV_HEADS: rows per batch item (1500)
+  int k_split;         // > 1 (256 x 128 kernel only): blockIdx.y takes K slice y of k_split equal slices
+  long split_stride;   // ... and writes to out + y * split_stride elements (raw partial sums: EPI_F32, no bias)
   float q_scale;       // EPI_QKV_ENC
   long vt_pitch;       // EPI_QKV_ENC: row pitch of the V^T image in elements (multiple of 64)
 };
