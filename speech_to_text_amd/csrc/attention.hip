@@ -40,7 +40,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 // ---------------------------------------------------------------------------------------------
 #define AE_K_BYTES (32 * 128)
 #define AE_TILE_BYTES (AE_K_BYTES + 64 * 72)
-__global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
+template <int NX>       // query halves of 32 per wave: 2, or 1 when that is what it takes to cover the chip
+__global__ __launch_bounds__(256, NX == 2 ? 2 : 3) void attn_encoder_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long ld, long batch_stride,
     const bf16_t* __restrict__ vt, long vt_pitch, bf16_t* __restrict__ out, int t, int heads,
     int n_batch, int nx, float lift_at) {
@@ -64,23 +65,23 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
   }
   const int b = pair / heads, h = pair - b * heads;
   __shared__ __attribute__((aligned(16))) unsigned char tile[2 * AE_TILE_BYTES];
-  const int q0 = xb * 256 + wave * 64;             // waves past the end still help stage the tiles
+  const int q0 = xb * (128 * NX) + wave * (32 * NX);             // waves past the end still help stage the tiles
   const int d_model = heads * 64;
   const bf16_t* qb = q + b * batch_stride + h * 64;
   const bf16_t* kb = k + b * batch_stride + h * 64;
   const bf16_t* vb = vt + (long)h * 64 * vt_pitch + (long)b * t;   // 8-byte aligned: t % 4 == 0
 
-  bf8_t qf[2][4];
+  bf8_t qf[NX][4];
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < NX; ++x) {
     int qi = q0 + 32 * x + c; qi = qi < t ? qi : t - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       qf[x][s] = __builtin_bit_cast(bf8_t, *(const uint4*)(qb + (long)qi * ld + 16 * s + 8 * hh));
   }
-  f16_t o[2][2], nref[2];                          // nref = -r in all sixteen registers
+  f16_t o[NX][2], nref[NX];                          // nref = -r in all sixteen registers
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < NX; ++x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) nref[x][r] = 0.f;
 #pragma unroll
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[x][dt][r] = 0.f;
   }
-  float lsum[2] = {0.f, 0.f};                      // this lane's half of the row sum
+  float lsum[NX];
+#pragma unroll
+  for (int x = 0; x < NX; ++x) lsum[x] = 0.f;                      // this lane's half of the row sum
 
   // The block's four waves walk the same keys, so a 32-key tile of K ([32][64], 128-byte rows,
   // 16-byte pieces XOR-swizzled by (row / 2) % 8: two rows fill the 256-byte bank row, and the rows
@@ -138,16 +141,16 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
         vf[dt][s2] = __builtin_bit_cast(bf8_t, uint4{lo.x, lo.y, hi.x, hi.y});
       }
     const bool first = it == 0, ragged = key0 + 32 > t;
-    f16_t sc[2];
+    f16_t sc[NX];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NX; ++x) {
       sc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[x][0], nref[x], 0, 0, 0);
 #pragma unroll
       for (int ss = 1; ss < 4; ++ss)
         sc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ss], qf[x][ss], sc[x], 0, 0, 0);
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NX; ++x) {
       f16_t& s = sc[x];
       if (ragged) {
 #pragma unroll
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
     __syncthreads();
   }
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < NX; ++x) {
     const int qi = q0 + 32 * x + c;
     const float l = lsum[x] + __shfl_xor(lsum[x], 32, 64);
     if (qi >= t) continue;
@@ -218,8 +221,16 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(
 void launch_attn_encoder(const bf16_t* q, const bf16_t* k, long ld, long batch_stride,
                          const bf16_t* vt, long vt_pitch, bf16_t* out, int batch, int t, int heads,
                          float lift_at, hipStream_t stream) {
+  // 256 queries per block, unless that leaves compute units without a block (one or two windows):
+  // then 128 queries per block (32 per wave, 9 % slower per score, twice the blocks)
   const int nx = (t + 255) / 256;
-  hipLaunchKernelGGL(attn_encoder_kernel, dim3(nx * heads * batch), dim3(256), 0, stream,
+  if ((long)nx * heads * batch <= 256) {
+    const int nx1 = (t + 127) / 128;
+    hipLaunchKernelGGL(attn_encoder_kernel<1>, dim3(nx1 * heads * batch), dim3(256), 0, stream,
+                       q, k, ld, batch_stride, vt, vt_pitch, out, t, heads, batch, nx1, lift_at);
+    return;
+  }
+  hipLaunchKernelGGL(attn_encoder_kernel<2>, dim3(nx * heads * batch), dim3(256), 0, stream,
                      q, k, ld, batch_stride, vt, vt_pitch, out, t, heads, batch, nx, lift_at);
 }
 
