@@ -401,7 +401,11 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
         const long at = (row0 + qc + qi) * d_model + h * 64 + d;
         if (a.q_slabs) {
           qv = a.q_bias ? a.q_bias[h * 64 + d] : 0.f;
-          for (int sl = 0; sl < a.n_q_slabs; ++sl) qv += a.q_slabs[sl * a.q_slab_stride + at];
+          float ps[8];                                   // at most 8 slabs: requested together, added in order
+#pragma unroll
+          for (int sl = 0; sl < 8; ++sl) ps[sl] = a.q_slabs[(sl < a.n_q_slabs ? sl : a.n_q_slabs - 1) * a.q_slab_stride + at];
+#pragma unroll
+          for (int sl = 0; sl < 8; ++sl) if (sl < a.n_q_slabs) qv += ps[sl];
         } else {
           qv = bf2f(a.q[at]);
         }

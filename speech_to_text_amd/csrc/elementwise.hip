@@ -38,9 +38,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     if (c < nv) {
       float4 t = ((const float4*)xr)[c];
       if (n_slabs > 0) {
-        for (int s = 0; s < n_slabs; ++s) {
-          const float4 p = ((const float4*)(slabs + s * slab_stride + in_row * d))[c];
-          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        // four slabs requested at a time, added in the order a plain loop would add them
+        for (int s0 = 0; s0 < n_slabs; s0 += 4) {
+          float4 p[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ss = s0 + j < n_slabs ? s0 + j : n_slabs - 1;
+            p[j] = ((const float4*)(slabs + ss * slab_stride + in_row * d))[c];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (s0 + j < n_slabs) { t.x += p[j].x; t.y += p[j].y; t.z += p[j].z; t.w += p[j].w; }
         }
         if (add_bias) {
           const float4 b = ((const float4*)add_bias)[c];
@@ -114,10 +122,17 @@ __global__ __launch_bounds__(256) void add_layernorm_row_kernel(
     if (c < nv) {
       float4 t = ((const float4*)xr)[c];
       if (n_slabs > 0) {
-        for (int s = 0; s < n_slabs; ++s) {
-          const float4 p = ((const float4*)(slabs + s * slab_stride + in_row * d))[c];
-          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        // at most 8 slabs (pick_split_k): all of them requested before the first is added, in the
+        // same order as a plain loop would add them
+        float4 p[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int ss = s < n_slabs ? s : n_slabs - 1;
+          p[s] = ((const float4*)(slabs + ss * slab_stride + in_row * d))[c];
         }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < n_slabs) { t.x += p[s].x; t.y += p[s].y; t.z += p[s].z; t.w += p[s].w; }
         if (add_bias) {
           const float4 b = ((const float4*)add_bias)[c];
           t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;

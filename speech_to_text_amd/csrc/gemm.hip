@@ -680,6 +680,214 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small-M kernel with the preceding LayerNorm as its prologue (M <= 4 rows: a single clip, greedy
+// or a few beams).  A decode step of that size is a chain of ~350 kernels of about 5 us each, and
+// most of those 5 us are the kernel boundary (dispatch, the first dependent load from memory,
+// the write-back at the end), not work: a LayerNorm of one row is such a kernel.  Here every block
+// computes the few rows' LayerNorm itself, into LDS, while its first weight loads are in flight,
+// and multiplies from there; the arithmetic and its order are those of add_layernorm_row_kernel
+// and gemm_skinny_kernel<1, NT, 1, EPI>, so both paths give the same bits.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(const GemmArgs g, const LnFuse f, int k_per_split,
+                                                             float* __restrict__ slabs) {
+  __shared__ f4_t part[3][NT][64];
+  __shared__ __attribute__((aligned(16))) bf16_t hs[4][2048];
+  __shared__ float sh[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int M = g.m, N = g.n, K = g.k, d = g.k;
+  const int kbeg = blockIdx.y * k_per_split;
+  const bf16_t* __restrict__ wrow[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    int wn = n0 + 16 * u + fr; wn = wn < N ? wn : N - 1;
+    wrow[u] = g.w + (long)wn * K + kbeg + 16 * fg;
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+  const int nsteps = k_per_split / 64;
+  const int nmy = (nsteps - wave + 3) >> 2;            // wave-uniform; this wave's steps are wave + 4 c
+  bf8_t wnext[NT][2];
+  auto load_w = [&](int c) {
+    const int s = wave + 4 * (c < nmy ? c : (nmy > 0 ? nmy - 1 : 0));
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      wnext[u][0] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64)));
+      wnext[u][1] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64 + 8)));
+    }
+  };
+  if (nmy > 0) load_w(0);                              // in flight during the prologue
+
+  // ---- prologue: LayerNorm of the M rows into hs (bf16), as add_layernorm_row_kernel does it
+  const int nv = d >> 2;
+  const bool writer = f.n_slabs > 0 && f.x_out != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  for (int m = 0; m < M; ++m) {
+    const long in_row = (long)m * f.row_mul + f.row_off;
+    const float* xr = f.x_in + in_row * d;
+    float4 v[2], gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      if (c < nv) {
+        gm[i] = ((const float4*)f.gamma)[c];
+        bt[i] = ((const float4*)f.beta)[c];
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      if (c < nv) {
+        float4 t = ((const float4*)xr)[c];
+        if (f.n_slabs > 0) {
+          float4 p[8];                                   // all requested before the first is added
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const int ss = s < f.n_slabs ? s : f.n_slabs - 1;
+            p[s] = ((const float4*)(f.slabs + ss * f.slab_stride + in_row * d))[c];
+          }
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+            if (s < f.n_slabs) { t.x += p[s].x; t.y += p[s].y; t.z += p[s].z; t.w += p[s].w; }
+          if (f.add_bias) {
+            const float4 b = ((const float4*)f.add_bias)[c];
+            t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+          }
+          if (writer) ((float4*)(f.x_out + in_row * d))[c] = t;
+        }
+        v[i] = t;
+        sum += t.x + t.y + t.z + t.w;
+      }
+    }
+    sum = gs_wave_sum(sum);
+    __syncthreads();                                   // sh is free again (previous row)
+    if (lane == 0) sh[wave] = sum;
+    __syncthreads();
+    const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      if (c < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+        sq += a * a + b * b + cc * cc + e * e;
+      }
+    }
+    sq = gs_wave_sum(sq);
+    if (lane == 0) sh[4 + wave] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((sh[4] + sh[5] + sh[6] + sh[7]) / d + f.eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      if (c < nv) {
+        const float4 gg = gm[i], b = bt[i];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gg.x + b.x;
+        o.y = (v[i].y - mean) * rstd * gg.y + b.y;
+        o.z = (v[i].z - mean) * rstd * gg.z + b.z;
+        o.w = (v[i].w - mean) * rstd * gg.w + b.w;
+        uint2 p;
+        p.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+        p.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+        ((uint2*)&hs[m][0])[c] = p;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the product, step by step as gemm_skinny_kernel<1, NT, 1, EPI> does it
+  f4_t acc[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc[u] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* hrow = &hs[fr < M ? fr : M - 1][kbeg + 16 * fg];
+  for (int c = 0; c < nmy; ++c) {
+    bf8_t wf[NT][2];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) { wf[u][0] = wnext[u][0]; wf[u][1] = wnext[u][1]; }
+    if (c + 1 < nmy) load_w(c + 1);
+    const int s = wave + 4 * c;
+    const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64));
+    const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64 + 8));
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][0], a0, acc[u], 0, 0, 0);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][1], a1, acc[u], 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) part[wave - 1][u][lane] = acc[u];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc[u] += part[0][u][lane] + part[1][u][lane] + part[2][u][lane];
+
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int n = n0 + 16 * u + 4 * fg;
+    if (n >= N) continue;
+    const int nv4 = N - n < 4 ? N - n : 4;
+    const int m = fr;
+    if (m >= M) continue;
+    float v[4] = {acc[u][0], acc[u][1], acc[u][2], acc[u][3]};
+    if (slabs) {
+      float* o = slabs + ((long)blockIdx.y * M + m) * N + n;
+      if (nv4 == 4) *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+      else for (int r = 0; r < nv4; ++r) o[r] = v[r];
+      continue;
+    }
+    if (g.bias) for (int r = 0; r < nv4; ++r) v[r] += g.bias[n + r];
+    if (EPI == EPI_GELU_BF16) for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], g.gelu_tanh);
+    const long o = (long)m * g.ldc + n;
+    if (EPI == EPI_F32) {
+      float* out = (float*)g.out;
+      for (int r = 0; r < nv4; ++r) out[o + r] = v[r];
+    } else {
+      bf16_t* out = (bf16_t*)g.out;
+      if (nv4 == 4 && ((o & 3) == 0)) {
+        uint2 p;
+        p.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        p.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *(uint2*)(out + o) = p;
+      } else {
+        for (int r = 0; r < nv4; ++r) out[o + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+template <int NT>
+static void launch_skinny_ln_nt(const GemmArgs& g, const LnFuse& f, int epilogue, int split_k, float* slabs_out,
+                                hipStream_t stream) {
+  dim3 grid((g.n + 16 * NT - 1) / (16 * NT), split_k, 1);
+  const int kps = g.k / split_k;
+  float* sl = split_k > 1 || epilogue < 0 ? slabs_out : nullptr;
+  if (sl) hipLaunchKernelGGL((gemm_skinny_ln_kernel<NT, EPI_F32>), grid, dim3(256), 0, stream, g, f, kps, sl);
+  else if (epilogue == EPI_GELU_BF16) hipLaunchKernelGGL((gemm_skinny_ln_kernel<NT, EPI_GELU_BF16>), grid, dim3(256), 0, stream, g, f, kps, sl);
+  else if (epilogue == EPI_F32) hipLaunchKernelGGL((gemm_skinny_ln_kernel<NT, EPI_F32>), grid, dim3(256), 0, stream, g, f, kps, sl);
+  else hipLaunchKernelGGL((gemm_skinny_ln_kernel<NT, EPI_BF16>), grid, dim3(256), 0, stream, g, f, kps, sl);
+}
+
+// same choice of features per block as launch_skinny_nt<1>
+void launch_gemm_skinny_ln(const GemmArgs& g, const LnFuse& f, int epilogue, int split_k, float* slabs_out,
+                           hipStream_t stream) {
+  const long blocks16 = (long)((g.n + 15) / 16) * split_k;
+  if (blocks16 >= 8 * 256) launch_skinny_ln_nt<4>(g, f, epilogue, split_k, slabs_out, stream);
+  else if (split_k == 1 && blocks16 >= 256 + SKINNY_NT2_MIN) launch_skinny_ln_nt<2>(g, f, epilogue, split_k, slabs_out, stream);
+  else launch_skinny_ln_nt<1>(g, f, epilogue, split_k, slabs_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Decode-step kernel for 32 < M <= 512 rows: a block owns 64 output features and up to 256 rows,
 // so the activations are read once per 64 features instead of once per 16.  Both operands go
 // through a three-stage LDS ring filled by LDS-DMA in K chunks of 64 (same 128-byte rows and

@@ -53,6 +53,28 @@ void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* sla
                         hipStream_t stream);
 int pick_split_k(int m, int n, int k, int n_cu);
 
+// The LayerNorm that produces a decode-step GEMM's input, done by the GEMM itself (rows <= 4):
+// every block repeats, for its own use, x_new = x_in + sum of pending slabs + add_bias and
+// h = LN(x_new) * gamma + beta (the arithmetic of launch_add_layernorm, operation for operation,
+// so the result does not depend on which of the two paths ran); block (0, 0) also stores x_new to
+// x_out, which must not be x_in (other blocks are still reading it).  With n_slabs == 0 nothing
+// is added and nothing is stored.  Input row of output row r: r * row_mul + row_off.
+struct LnFuse {
+  const float* x_in;
+  float* x_out;
+  const float* slabs;
+  int n_slabs;
+  long slab_stride;
+  const float* add_bias;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int row_mul, row_off;
+};
+// g.a is ignored; g.m <= 4, g.k == the width d of x (<= 2048, a multiple of 64).
+void launch_gemm_skinny_ln(const GemmArgs& g, const LnFuse& f, int epilogue, int split_k, float* slabs_out,
+                           hipStream_t stream);
+
 // ---------------------------------------------------------------- normalisation / elementwise
 // x[m][d] += sum_s slabs[s][m][d] + add_bias[d] (both optional), then out = LN(x) * gamma + beta.
 // Output row r is computed from input row r * row_mul + row_off (row_mul = 1, row_off = 0 for a
