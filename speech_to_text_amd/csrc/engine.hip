@@ -211,10 +211,12 @@ GemmArgs gemm_args(const bf16_t* a, long lda, const bf16_t* w, const float* bias
 // Up to this many rows a layer goes through the decode-step kernels (weights streamed once, split-K
 // partial sums consumed by the next kernel); above it through the tiled large-M kernels.
 constexpr int kDecodeRows = 512;
-// Up to this many rows (a single clip: greedy, or a few beams) the three LayerNorms of a decoder
-// layer and the final one run as the prologue of the projection that consumes them
-// (launch_gemm_skinny_ln): 8 instead of 11 launches per layer, same bits.
-constexpr int kLnFuseRows = 4;
+// With a single row (one clip, greedy: the way the reference calls) the three LayerNorms of a
+// decoder layer and the final one run as the prologue of the projection that consumes them
+// (launch_gemm_skinny_ln): 8 instead of 11 launches per layer, same bits, 1.96 -> 1.80 ms per token
+// at large-v3.  The prologue handles its rows one after the other, so from two rows on the separate
+// one-block-per-row kernel is faster (2.02 against 2.11 ms per token at two rows, 2.09 against 2.70 at four).
+constexpr int kLnFuseRows = 1;
 
 void dense(stt_engine* e, const bf16_t* a, long lda, const bf16_t* w, const float* bias, int rows,
            int n, int k, int epilogue, void* out, long ldc, int* pending_slabs, hipStream_t st) {

@@ -715,16 +715,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(const GemmArgs g, c
   typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
   const int nsteps = k_per_split / 64;
   const int nmy = (nsteps - wave + 3) >> 2;            // wave-uniform; this wave's steps are wave + 4 c
-  bf8_t wnext[NT][2];
-  auto load_w = [&](int c) {
+  // Weights: with one or two feature tiles per block every step of this wave (at most 8: K <= 2048)
+  // is requested here, so that all of them travel while the prologue runs; with four tiles that
+  // would take 256 registers, and the loop requests one step ahead instead.
+  constexpr int kPre = NT <= 2 ? 8 : 1;
+  bf8_t wpre[kPre][NT][2];
+  auto load_w = [&](int slot, int c) {
     const int s = wave + 4 * (c < nmy ? c : (nmy > 0 ? nmy - 1 : 0));
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      wnext[u][0] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64)));
-      wnext[u][1] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64 + 8)));
+      wpre[slot][u][0] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64)));
+      wpre[slot][u][1] = __builtin_bit_cast(bf8_t, __builtin_nontemporal_load((const u4_t*)(wrow[u] + s * 64 + 8)));
     }
   };
-  if (nmy > 0) load_w(0);                              // in flight during the prologue
+  if (kPre == 8) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < nmy) load_w(c, c);
+  } else if (nmy > 0) {
+    load_w(0, 0);
+  }
 
   // ---- prologue: LayerNorm of the M rows into hs (bf16), as add_layernorm_row_kernel does it
   const int nv = d >> 2;
@@ -809,18 +818,34 @@ __global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(const GemmArgs g, c
 #pragma unroll
   for (int u = 0; u < NT; ++u) acc[u] = f4_t{0.f, 0.f, 0.f, 0.f};
   const bf16_t* hrow = &hs[fr < M ? fr : M - 1][kbeg + 16 * fg];
-  for (int c = 0; c < nmy; ++c) {
-    bf8_t wf[NT][2];
+  if (kPre == 8) {
 #pragma unroll
-    for (int u = 0; u < NT; ++u) { wf[u][0] = wnext[u][0]; wf[u][1] = wnext[u][1]; }
-    if (c + 1 < nmy) load_w(c + 1);
-    const int s = wave + 4 * c;
-    const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64));
-    const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64 + 8));
+    for (int c = 0; c < 8; ++c) {
+      if (c < nmy) {
+        const int s = wave + 4 * c;
+        const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64));
+        const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64 + 8));
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][0], a0, acc[u], 0, 0, 0);
-      acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][1], a1, acc[u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) {
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpre[c][u][0], a0, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpre[c][u][1], a1, acc[u], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < nmy; ++c) {
+      bf8_t wf[NT][2];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) { wf[u][0] = wpre[0][u][0]; wf[u][1] = wpre[0][u][1]; }
+      if (c + 1 < nmy) load_w(0, c + 1);
+      const int s = wave + 4 * c;
+      const bf8_t a0 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64));
+      const bf8_t a1 = __builtin_bit_cast(bf8_t, *(const uint4*)(hrow + s * 64 + 8));
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][0], a0, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][1], a1, acc[u], 0, 0, 0);
+      }
     }
   }
   if (wave > 0) {
@@ -1072,9 +1097,10 @@ int pick_split_k(int m, int n, int k, int n_cu) {
     return best;
   }
   const int col_blocks = (n + 15) / 16;
+  static const int min_steps = getenv("STT_MI355X_SKINNY_MINSTEPS") ? atoi(getenv("STT_MI355X_SKINNY_MINSTEPS")) : 4;
   for (int s = 1; s <= 8 && s <= steps; ++s) {
     if (steps % s) continue;
-    if (steps / s < 8) break;              // at least two steps per wave
+    if (steps / s < min_steps) break;      // at least one step per wave (8 measured slower: 1.93 against 1.87 ms per token, one clip)
     best = s;
     if ((long)col_blocks * s >= 2L * n_cu) break;
   }
