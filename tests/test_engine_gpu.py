@@ -470,6 +470,27 @@ def test_beam_search_finished_beams(small):
         assert np.array_equal(el, fl) and np.allclose(es, fs, atol=1e-5)
 
 
+def test_single_row_path_matches_batched_bits_and_oracle(small):
+    """One clip decoded alone takes the one-row path of the decode step (every LayerNorm inside the
+    projection that consumes it); the same clip decoded with two others takes the separate
+    kernels.  The arithmetic is the same operation for operation: identical tokens and scores, and
+    one-token logits within the stated tolerance of the oracle."""
+    dims, engine, oracle, mel = small
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    kw = dict(max_new_tokens=12, eos_token=999, pad_token=999, early_stopping=False)
+    engine.encode(mel)
+    t3, _, s3 = engine.generate(prompt, **kw)
+    engine.encode(mel[:1])
+    t1, _, s1 = engine.generate(prompt[:1], **kw)
+    assert np.array_equal(t1[0], t3[0]) and s1[0] == s3[0]
+    tok = np.array([[7]], dtype=np.int32)
+    got = engine.decoder_logits(tok).cpu().numpy()                   # 1 sequence x 1 token = one row
+    with torch.no_grad():
+        enc = oracle.encoder(mel[:1])
+        ref, _ = oracle.decoder(torch.from_numpy(tok).long(), oracle.cross_kv(enc))
+    assert _rel_l2(got, ref.numpy()) < 2e-2
+
+
 def test_reserve_keeps_weights_and_cached_graphs_replay(small):
     """stt_engine_reserve grows the buffers without touching the weights: same tokens before and
     after; a second call with the same configuration replays the cached token-step graph, a
