@@ -439,8 +439,17 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
 #pragma unroll
         for (int qi = 0; qi < CQ; ++qi) {
           float sv = 0.f;
+          if (CQ == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sv += kv[e] * qr[qi][e];
+            for (int e = 0; e < 8; ++e) sv += kv[e] * qr[qi][e];
+          } else {
+            // several queries per key are bound by the vector unit, not by the stream: the dot
+            // product as four packed multiply-adds (even and odd elements in two chains)
+            f2_t s2 = f2_t{0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) s2 += f2_t{kv[e], kv[e + 1]} * f2_t{qr[qi][e], qr[qi][e + 1]};
+            sv = s2[0] + s2[1];
+          }
           sv = sum8(sv);
           if (key < T) {
             mx[qi] = fmaxf(mx[qi], sv);
@@ -489,8 +498,16 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
         for (int qi = 0; qi < CQ; ++qi) {
           const float pw = key < T ? __expf(sc[qi][key] - mx[qi]) : 0.f;
           sum[qi] += pw;
+          if (CQ == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[qi][e] += pw * vv[e];
+            for (int e = 0; e < 8; ++e) acc[qi][e] += pw * vv[e];
+          } else {                 // the same products and sums, two per instruction
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const f2_t r = f2_t{acc[qi][e], acc[qi][e + 1]} + f2_t{pw, pw} * f2_t{vv[e], vv[e + 1]};
+              acc[qi][e] = r[0]; acc[qi][e + 1] = r[1];
+            }
+          }
         }
       }
     }
