@@ -153,6 +153,13 @@ int stt_engine_finalize(stt_engine* engine);
  * from window to window (models/stt/whisper.py:238-243) reserves once for the worst case. */
 int stt_engine_reserve(stt_engine* engine, int max_batch, int max_beams, int max_text_len,
                        int max_prompt_len);
+/* When the new buffers do not fit the device, stt_engine_reserve returns STT_ERR_HIP and the engine
+ * is back at the capacity it had (buffers allocated afresh, encoded batch lost); if even those no
+ * longer fit it holds its weights and no buffers, every compute entry point returns
+ * STT_ERR_INVALID_ARGUMENT, and a later stt_engine_reserve that fits revives it.
+ * stt_engine_usable: 1 when the engine is finalized and holds its buffers, else 0.  (The reference
+ * leaves allocation failures to its backend: no counterpart.) */
+int stt_engine_usable(const stt_engine* engine);
 
 /* d_mel: [batch][frames][n_mels] float32 on the device, frames <= 3000; shorter
  * windows are padded with 0.0 (BaseSTT.pad_or_trim, models/stt/base_stt.py:227-236).
@@ -168,6 +175,26 @@ int stt_encode(stt_engine* engine, const float* d_mel, int batch, int frames, fl
  * [batch][n_tokens][n_vocab] float32.  Synchronises the stream. */
 int stt_decoder_forward(stt_engine* engine, const int32_t* tokens, int batch, int n_tokens,
                         float* d_logits, void* stream);
+
+/* One cached decoder step with the token selection left to the caller: what generation_utils.py
+ * calls `step_fn` inside its loop bodies (architectures/generation_utils.py:201-223, 338-358) -
+ * the decoder over the new tokens with `initial_state` = the K/V cache, logits of the last
+ * position out, K/V of the new tokens appended (:274-277, 693-725).  It is the route for what
+ * cannot run inside stt_generate's device loop: an arbitrary Python `logits_filter`
+ * (:518-520), per-step logits under beam search (:422-428).
+ *  n_seq = windows of the last stt_encode x seq_per_window (sequences of one window are
+ *   consecutive and share its cross-attention K/V; seq_per_window <= max_beams).
+ *  d_tokens: device int32 [n_seq][n_tokens], the new tokens of every sequence (the prompt on the
+ *   first call, one token afterwards; every sequence advances by the same n_tokens).
+ *  reset != 0: the sequences start empty.  Otherwise the call continues the history of the
+ *   previous stt_decode_step calls (same n_seq); stt_encode and stt_generate end a history.
+ *  d_parents: NULL, or device int32 [n_seq]: before the step, sequence i takes over the history
+ *   of sequence d_parents[i] (beam search's gather of the decoder state by beam index,
+ *   generation_utils.py:658-676; here the cache is re-linked, not copied).
+ *  d_logits: device float32 [n_seq][n_vocab], raw logits of the last new position.
+ * Enqueues on `stream` and returns; nothing is synchronised. */
+int stt_decode_step(stt_engine* engine, const int32_t* d_tokens, int n_seq, int seq_per_window,
+                    int n_tokens, int reset, const int32_t* d_parents, float* d_logits, void* stream);
 
 /* Measurement aid, no counterpart in the reference: enqueues on `stream` one launch of a hot
  * kernel exactly as a greedy token step over the last encoded batch issues it, so that a

@@ -36,6 +36,7 @@ struct stt_engine {
   int max_batch = 0, max_beams = 0, max_len = 0, max_prompt = 0;
   int device = 0, n_cu = 256;
   bool finalized = false;
+  bool buffers_ok = false;             // false after a failed (re-)allocation: every entry point then refuses
   hipStream_t gen_stream = nullptr;    // generation runs here: a captured token step needs a real stream
   hipEvent_t gen_event = nullptr;
   std::map<std::string, std::vector<float>> host_w;
@@ -60,6 +61,7 @@ struct stt_engine {
   float* eslabs = nullptr;  // split-K partial sums of the encoder's residual projections (a few windows only)
   std::vector<bf16_t*> cross_k, cross_v;
   int enc_batch = 0;       // windows held by the last stt_encode
+  int step_len = 0, step_seqs = 0;   // stt_decode_step: positions in the cache, sequences of the history
 
   // decoder buffers
   int max_seq = 0, max_rows = 0;
@@ -409,7 +411,8 @@ int stt_engine_finalize(stt_engine* e) {
 
   e->finalized = true;
   rc = alloc_buffers(e);
-  if (rc) e->finalized = false;
+  e->buffers_ok = rc == STT_OK;
+  if (rc) { free_buffers(e); (void)hipGetLastError(); }   // weights stay: stt_engine_reserve with a capacity that fits may retry
   return rc;
 }
 
@@ -420,15 +423,35 @@ int stt_engine_reserve(stt_engine* e, int max_batch, int max_beams, int max_text
   const int nm = max_beams > e->max_beams ? max_beams : e->max_beams;
   const int nl = max_text_len > e->max_len ? max_text_len : e->max_len;
   const int np = max_prompt_len > e->max_prompt ? max_prompt_len : e->max_prompt;
-  if (nb == e->max_batch && nm == e->max_beams && nl == e->max_len && np == e->max_prompt) return STT_OK;
+  if (e->buffers_ok && nb == e->max_batch && nm == e->max_beams && nl == e->max_len && np == e->max_prompt)
+    return STT_OK;
   if (nm > 16 || nl > e->cfg.n_text_ctx || nl > 512 || np >= nl || nb < 1)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "bad capacity (batch %d, beams %d, text %d, prompt %d)", nb, nm, nl, np);
   STT_HIP_OR_FAIL(hipDeviceSynchronize(), (void)0);        // nothing may still read the old buffers
   free_buffers(e);
+  const int ob = e->max_batch, om = e->max_beams, ol = e->max_len, op = e->max_prompt;
+  const bool had = e->buffers_ok;
   e->max_batch = nb; e->max_beams = nm; e->max_len = nl; e->max_prompt = np;
   e->enc_batch = 0;
-  return alloc_buffers(e);
+  e->buffers_ok = false;
+  int rc = alloc_buffers(e);
+  if (rc == STT_OK) { e->buffers_ok = true; return STT_OK; }
+  // Out of memory part-way: nothing half-allocated may stay reachable.  Go back to the capacity
+  // that did fit (its buffers are gone, so they are allocated afresh); if even that fails the
+  // engine keeps its weights but refuses encode / generate until a reserve succeeds.
+  const std::string why = stt_last_error();
+  free_buffers(e);
+  (void)hipGetLastError();               // the failed hipMalloc must not surface in a later call's check
+  e->max_batch = ob; e->max_beams = om; e->max_len = ol; e->max_prompt = op;
+  if (had && alloc_buffers(e) == STT_OK) e->buffers_ok = true;
+  else free_buffers(e);
+  return stt_fail(rc, "stt_engine_reserve(batch %d, beams %d, text %d, prompt %d) failed: %s; the engine %s",
+                  nb, nm, nl, np, why.c_str(),
+                  e->buffers_ok ? "keeps its previous capacity (encode again before decoding)"
+                                : "holds no buffers until a reserve succeeds");
 }
+
+int stt_engine_usable(const stt_engine* e) { return e && e->finalized && e->buffers_ok ? 1 : 0; }
 
 }  // extern "C"
 
@@ -459,6 +482,7 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
   hipStream_t st = (hipStream_t)stream_;
   if (!e || !d_mel) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (!e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine holds no buffers (an allocation failed)");
   if (batch < 1 || batch > e->max_batch || frames < 1 || frames > 3000)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d (max %d) / frames %d (max 3000) out of range",
                     batch, e->max_batch, frames);
@@ -475,6 +499,12 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
     if (f > 0.f && f <= 100.f) lift_at = f;
   }
 
+  // The attention kernel's last key tile of the last window reads up to 64 positions past the
+  // batch in every row of the V^T image (under zero weights).  In a smaller batch than an earlier
+  // one those positions hold that call's data: clear them, so that a non-finite value left there
+  // cannot reach this call through 0 * NaN.
+  STT_HIP_OR_FAIL(hipMemset2DAsync(e->evt + (size_t)batch * T, (size_t)vt_pitch(e) * sizeof(bf16_t), 0,
+                                   64 * sizeof(bf16_t), (size_t)H * 64, st), (void)0);
   launch_pack_mel(d_mel, batch, frames, c.n_mels, e->mel_pad, st);
   {   // conv1: rows (b, t) start at mel_pad[b][t], K = 3 * n_mels (zero-padded weights beyond)
     GemmArgs g = gemm_args(e->mel_pad, c.n_mels, e->conv1_w, e->conv1_b, e->h1_pad + d, d, 3000, d,
@@ -523,6 +553,7 @@ int stt_encode(stt_engine* e, const float* d_mel, int batch, int frames, float* 
     launch_gemm_big(gkv, EPI_KV_HEADS, st);
   }
   e->enc_batch = batch;
+  e->step_len = e->step_seqs = 0;
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
 }
@@ -535,7 +566,8 @@ namespace {
 // device).  last_only: logits of the last new token of every sequence -> gs.logits [n_seq][V];
 // otherwise logits of every row -> d_all_logits [rows][V].
 int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last_only,
-                 float* d_all_logits, hipStream_t st) {
+                 float* d_all_logits, hipStream_t st, float* d_last_logits = nullptr) {
+  float* last_dst = d_last_logits ? d_last_logits : e->gs.logits;
   const stt_model_config& c = e->cfg;
   const int d = c.n_text_state, H = c.n_text_head, V = c.n_vocab;
   const int rows = n_seq * s_new;
@@ -608,13 +640,13 @@ int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last
     const int out_rows = last_only ? n_seq : rows;
     LnFuse f{xcur, nullptr, e->slabs, pend, slab_stride, pend ? pend_bias : nullptr, e->dec_lng, e->dec_lnb, 1e-5f,
              last_only ? s_new : 1, last_only ? s_new - 1 : 0};
-    GemmArgs g = gemm_args(nullptr, d, e->tok_emb, nullptr, last_only ? (void*)e->gs.logits : (void*)d_all_logits, V,
+    GemmArgs g = gemm_args(nullptr, d, e->tok_emb, nullptr, last_only ? (void*)last_dst : (void*)d_all_logits, V,
                            out_rows, V, d, gt);
     launch_gemm_skinny_ln(g, f, EPI_F32, 1, nullptr, st);
   } else if (last_only) {
     launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, e->dec_lng, e->dec_lnb, e->dh,
                          nullptr, n_seq, d, 1e-5f, s_new, s_new - 1, st);
-    dense(e, e->dh, d, e->tok_emb, nullptr, n_seq, V, d, EPI_F32, e->gs.logits, V, nullptr, st);
+    dense(e, e->dh, d, e->tok_emb, nullptr, n_seq, V, d, EPI_F32, last_dst, V, nullptr, st);
   } else {
     launch_add_layernorm(e->dx, e->slabs, pend, slab_stride, pend_bias, e->dec_lng, e->dec_lnb, e->dh,
                          nullptr, rows, d, 1e-5f, 1, 0, st);
@@ -632,6 +664,32 @@ __global__ void init_state_kernel(GenState s, int n_seq, int prompt_len, int max
   }
   for (int p = threadIdx.x; p < max_len; p += blockDim.x) s.slot_of[(long)i * max_len + p] = i;
 }
+// stt_decode_step: positions of the new tokens, and the cache bookkeeping around the pass
+__global__ void step_positions_kernel(const int* base_len, int* positions, int n_seq, int n_tokens) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_seq * n_tokens) positions[r] = base_len[r / n_tokens] + r % n_tokens;
+}
+__global__ void advance_len_kernel(int* base_len, int n_seq, int n_tokens) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seq) base_len[i] += n_tokens;
+}
+// Sequence i continues the history of sequence parents[i]: positions the parent's history covers
+// keep the cache slots the parent read them from, later ones will be written by i itself.
+__global__ void relink_kernel(GenState s, const int* parents, int n_seq, int max_len) {
+  const int i = blockIdx.x;
+  int p = parents[i];
+  if (p < 0 || p >= n_seq) p = i;
+  const int len = s.base_len[p];
+  for (int q = threadIdx.x; q < max_len; q += blockDim.x)
+    s.slot_of_tmp[(long)i * max_len + q] = q < len ? s.slot_of[(long)p * max_len + q] : i;
+  if (threadIdx.x == 0) s.lengths_tmp[i] = len;
+}
+__global__ void relink_commit_kernel(GenState s, int max_len) {
+  const int i = blockIdx.x;
+  for (int q = threadIdx.x; q < max_len; q += blockDim.x)
+    s.slot_of[(long)i * max_len + q] = s.slot_of_tmp[(long)i * max_len + q];
+  if (threadIdx.x == 0) s.base_len[i] = s.lengths_tmp[i];
+}
 __global__ void fill_int_kernel(int* p, long n, int v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -645,6 +703,7 @@ int stt_decoder_forward(stt_engine* e, const int32_t* tokens, int batch, int n_t
   hipStream_t st = (hipStream_t)stream_;
   if (!e || !tokens || !d_logits) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (!e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine holds no buffers (an allocation failed)");
   if (batch != e->enc_batch)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d differs from the encoded batch %d", batch, e->enc_batch);
   if (n_tokens < 1 || n_tokens > e->max_len || batch * n_tokens > e->max_rows)
@@ -660,9 +719,46 @@ int stt_decoder_forward(stt_engine* e, const int32_t* tokens, int batch, int n_t
   return STT_OK;
 }
 
+int stt_decode_step(stt_engine* e, const int32_t* d_tokens, int n_seq, int seq_per_window, int n_tokens,
+                    int reset, const int32_t* d_parents, float* d_logits, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !d_tokens || !d_logits) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (!e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine holds no buffers (an allocation failed)");
+  if (seq_per_window < 1 || seq_per_window > e->max_beams || n_seq < 1 || n_seq % seq_per_window ||
+      n_seq / seq_per_window != e->enc_batch)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "%d sequences at %d per window do not match the encoded batch %d "
+                    "(at most %d per window)", n_seq, seq_per_window, e->enc_batch, e->max_beams);
+  if (reset) e->step_len = 0;
+  else if (e->step_seqs != n_seq)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "%d sequences, but the history was started with %d (reset first)",
+                    n_seq, e->step_seqs);
+  if (n_tokens < 1 || e->step_len + n_tokens > e->max_len || (long)n_seq * n_tokens > e->max_rows)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "%d new tokens after %d exceed the engine capacity (%d positions, "
+                    "%d rows per pass)", n_tokens, e->step_len, e->max_len, e->max_rows);
+  if (reset) {
+    hipLaunchKernelGGL(init_state_kernel, dim3(n_seq), dim3(64), 0, st, e->gs, n_seq, 0, e->max_len);
+  } else if (d_parents) {
+    hipLaunchKernelGGL(relink_kernel, dim3(n_seq), dim3(256), 0, st, e->gs, d_parents, n_seq, e->max_len);
+    hipLaunchKernelGGL(relink_commit_kernel, dim3(n_seq), dim3(256), 0, st, e->gs, e->max_len);
+  }
+  const int rows = n_seq * n_tokens;
+  STT_HIP_OR_FAIL(hipMemcpyAsync(e->tokens_in, d_tokens, (size_t)rows * 4, hipMemcpyDeviceToDevice, st), (void)0);
+  hipLaunchKernelGGL(step_positions_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, e->gs.base_len,
+                     e->positions, n_seq, n_tokens);
+  int rc = decoder_pass(e, n_seq, seq_per_window, n_tokens, true, nullptr, st, d_logits);
+  if (rc) return rc;
+  hipLaunchKernelGGL(advance_len_kernel, dim3((n_seq + 255) / 256), dim3(256), 0, st, e->gs.base_len, n_seq,
+                     n_tokens);
+  e->step_len += n_tokens;
+  e->step_seqs = n_seq;
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
 int stt_engine_probe_kernel(stt_engine* e, int kernel, int layer, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  if (!e || !e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (!e || !e->finalized || !e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
   if (e->enc_batch < 1) return stt_fail(STT_ERR_INVALID_ARGUMENT, "nothing encoded");
   if (layer < 0 || layer >= e->cfg.n_text_layer) return stt_fail(STT_ERR_INVALID_ARGUMENT, "no such layer");
   const int d = e->cfg.n_text_state, H = e->cfg.n_text_head;
@@ -692,6 +788,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   if (!e || !p || !prompt || !out_tokens || !out_lengths || !out_scores)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   if (!e->finalized) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (!e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine holds no buffers (an allocation failed)");
   if (batch != e->enc_batch)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "batch %d differs from the encoded batch %d", batch, e->enc_batch);
   const int beams = p->method == STT_METHOD_BEAM ? p->num_beams : 1;
@@ -707,6 +804,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   if (p->n_suppress > e->suppress_cap || p->n_suppress_first > e->suppress_cap)
     return stt_fail(STT_ERR_INVALID_ARGUMENT, "too many suppressed tokens");
   const int n_seq = batch * beams, V = e->cfg.n_vocab, max_steps = p->max_steps;
+  e->step_len = e->step_seqs = 0;          // the cache is taken over: a stt_decode_step history ends here
   if (p->d_logits_out && p->method != STT_METHOD_GREEDY)
     return stt_fail(STT_ERR_UNSUPPORTED, "d_logits_out (return_logits) is implemented for greedy search only");
   GenState gs = e->gs;

@@ -59,6 +59,34 @@ class TimestampFilter(object):
         self.eos_token_idx = int(eos_token_idx)
         self.max_initial_timestamp = int(max_initial_timestamp)
 
+    def as_callable(self):
+        """The same rules as a function of torch tensors, for the loop that selects in Python
+        (eager.py): `f(scores [n, V], tokens = generated [n, steps], state = LoopState)`.  Written as
+        whole-tensor masks, so nothing is read back to the host; restates
+        models/stt/whisper.py:354-416."""
+        first = torch.from_numpy(self.remove_tokens_with_space.astype(np.int64))
+        later = torch.from_numpy(self.remove_tokens.astype(np.int64))
+        begin, eos, max_init = self.timestamp_begin_idx, self.eos_token_idx, self.max_initial_timestamp
+
+        def rules(scores, tokens, state, **_):
+            ninf = float("-inf")
+            ids = torch.arange(scores.shape[-1], device=scores.device)[None]
+            if state.state is None:
+                ban = ids < begin
+                if max_init > 0:
+                    ban = ban | (ids >= begin + max_init)
+                return scores.index_fill(1, first.to(scores.device), ninf).masked_fill(ban, ninf)
+            t = int(state.t)
+            scores = scores.index_fill(1, later.to(scores.device), ninf)
+            last = tokens[:, t - 1] >= begin
+            before = tokens[:, t - 2] >= begin if t >= 2 else torch.ones_like(last)
+            scores = scores.masked_fill((last & ~before)[:, None] & (ids < eos), ninf)
+            scores = scores.masked_fill((last & before)[:, None] & (ids >= begin), ninf)
+            logp = torch.log_softmax(scores, dim=-1)
+            stamp = torch.logsumexp(logp[:, begin:], dim=-1) > logp[:, :begin].max(dim=-1).values
+            return scores.masked_fill(stamp[:, None] & (ids < begin), ninf)
+        return rules
+
     @classmethod
     def from_callable(cls, fn):
         """The reference enables its timestamp rules by handing `generation_utils.infer` a callable
@@ -123,7 +151,10 @@ class WhisperEngine(object):
             pass
 
     def reserve(self, max_batch=0, max_beams=0, max_text_len=0, max_prompt_len=0):
-        """Grow the capacity (weights stay where they are); the encoded batch is dropped."""
+        """Grow the capacity (weights stay where they are); the encoded batch is dropped.  When the
+        new buffers do not fit the card the call raises and the engine is back at its previous
+        capacity (or, if even that no longer fits, unusable until a reserve succeeds: `usable()`)."""
+        self._batch = 0
         with torch.cuda.device(self.device):
             _lib.check(self._lib.stt_engine_reserve(self._h, int(max_batch), int(max_beams),
                                                     int(max_text_len), int(max_prompt_len)))
@@ -131,6 +162,10 @@ class WhisperEngine(object):
         self.max_text_len = max(self.max_text_len, int(max_text_len))
         self.max_prompt_len = max(self.max_prompt_len, int(max_prompt_len))
         self._batch = 0
+
+    def usable(self):
+        """False after an allocation failure that left the engine without buffers."""
+        return bool(self._lib.stt_engine_usable(self._h))
 
     def probe_kernel(self, kernel=0, layer=0):
         """One launch of a hot kernel on the current stream (stt_engine_probe_kernel): for timing."""
@@ -175,17 +210,46 @@ class WhisperEngine(object):
                 self._h, tokens.ctypes.data_as(C.POINTER(C.c_int32)), b, s, out.data_ptr(), self._stream()))
         return out
 
+    def decode_step(self, tokens, seq_per_window=1, reset=False, parents=None):
+        """One cached decoder step (stt_decode_step): `tokens` int32 [n_seq, n_tokens] (CUDA tensor or
+        array) are appended to the sequences' histories and the logits of the last position come
+        back as a float32 CUDA tensor [n_seq, V].  `reset` starts the histories afresh (the prompt);
+        `parents` int32 [n_seq] re-links sequence i to the history of sequence parents[i] first
+        (beam search).  Selection is the caller's: see speech_to_text_amd/eager.py."""
+        if not isinstance(tokens, torch.Tensor):
+            tokens = torch.from_numpy(np.ascontiguousarray(np.asarray(tokens, dtype=np.int32)))
+        tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        if tokens.dim() == 1:
+            tokens = tokens[:, None]
+        n_seq, n_tok = tokens.shape
+        if parents is not None:
+            if not isinstance(parents, torch.Tensor):
+                parents = torch.from_numpy(np.ascontiguousarray(np.asarray(parents, dtype=np.int32)))
+            parents = parents.to(device=self.device, dtype=torch.int32).contiguous()
+            if parents.numel() != n_seq:
+                raise ValueError("parents must name one sequence per sequence")
+        with torch.cuda.device(self.device):
+            out = torch.empty((n_seq, self.dims["n_vocab"]), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.stt_decode_step(
+                self._h, tokens.data_ptr(), n_seq, int(seq_per_window), n_tok, 1 if reset else 0,
+                parents.data_ptr() if parents is not None else None, out.data_ptr(), self._stream()))
+        return out
+
     def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
                  eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
                  length_power=None, logits_filter=None, check_every=8, sample=None, seed=None,
-                 return_logits=False):
+                 return_logits=False, filter_kwargs=None):
         """`temperature` given (and not 0) means, as in the reference (generation_utils.py:538-548),
         that tokens are drawn from the categorical distribution of the processed scores instead of
         taking the argmax / top-k; `sample = False` keeps the rescaling but not the draw.  `seed`
         makes the draws repeatable (default: fresh entropy per call, like the reference's
-        unseeded `keras.random.categorical`).  `return_logits` (greedy only) appends a CUDA tensor
-        [batch, max_new_tokens, n_vocab] with the processed scores of every step to the result
-        (generation_utils.py:266-268, 297); rows of steps after an early stop are -inf."""
+        unseeded `keras.random.categorical`).  `return_logits` appends a CUDA tensor
+        [batch, (num_sentences,) max_new_tokens, n_vocab] with the processed scores of every step to
+        the result (generation_utils.py:266-268, 297, 422-428); rows of steps after an early stop are
+        -inf.  `logits_filter`: a list of token ids, a TimestampFilter, the reference's Whisper filter
+        bound to a model (all three run inside the device loop), or any other callable
+        `f(scores, tokens = ..., state = ..., **filter_kwargs)` on CUDA tensors, which - like
+        `return_logits` under beam search - runs the loop in Python over `decode_step` (eager.py)."""
         prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
         if prompt.ndim == 1:
             prompt = prompt[None]
@@ -212,13 +276,32 @@ class WhisperEngine(object):
             p.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
         keep = []
         if callable(logits_filter) and not isinstance(logits_filter, TimestampFilter):
+            # the reference's own Whisper filter is recognised and runs inside the device loop; any
+            # other callable gets the scores of every step as a CUDA tensor (eager.py)
             translated = TimestampFilter.from_callable(logits_filter)
             if translated is None:
-                raise ValueError("logits_filter: only the reference's Whisper `logits_filter` / "
-                                 "`timestamp_filter` bound to a model (functools.partial or bound "
-                                 "method) can be translated to the device loop; pass that, a "
-                                 "TimestampFilter or a list of token ids")
+                from . import eager
+                return eager.generate(
+                    self, prompt, method=method, num_beams=num_beams, num_sentences=num_sentences,
+                    max_new_tokens=max_new_tokens, eos_token=eos_token, pad_token=pad_token,
+                    early_stopping=early_stopping, temperature=temperature,
+                    length_temperature=length_temperature, length_power=length_power,
+                    logits_filter=logits_filter, return_logits=return_logits, seed=seed,
+                    check_every=check_every, filter_kwargs=filter_kwargs)
             logits_filter = translated
+        if return_logits and beam:
+            # per-step scores gathered by beam index (generation_utils.py:422-428): eager loop,
+            # with the timestamp rules as a torch function when they are asked for
+            from . import eager
+            if isinstance(logits_filter, TimestampFilter):
+                logits_filter = logits_filter.as_callable()
+            return eager.generate(
+                self, prompt, method=method, num_beams=num_beams, num_sentences=num_sentences,
+                max_new_tokens=max_new_tokens, eos_token=eos_token, pad_token=pad_token,
+                early_stopping=early_stopping, temperature=temperature,
+                length_temperature=length_temperature, length_power=length_power,
+                logits_filter=logits_filter, return_logits=True, seed=seed, check_every=check_every,
+                filter_kwargs=filter_kwargs)
         if isinstance(logits_filter, TimestampFilter):
             a, bb = logits_filter.remove_tokens, logits_filter.remove_tokens_with_space
             keep += [a, bb]
@@ -238,8 +321,6 @@ class WhisperEngine(object):
         logits = None
         with torch.cuda.device(self.device):
             if return_logits:
-                if beam:
-                    raise ValueError("return_logits is implemented for greedy search")
                 logits = torch.full((b, p.max_steps, self.dims["n_vocab"]), float("-inf"),
                                     dtype=torch.float32, device=self.device)
                 p.d_logits_out = logits.data_ptr()
@@ -272,6 +353,10 @@ def _declare(lib):
     lib.stt_engine_finalize.argtypes = [vp]
     lib.stt_engine_reserve.restype = i32
     lib.stt_engine_reserve.argtypes = [vp, i32, i32, i32, i32]
+    lib.stt_engine_usable.restype = i32
+    lib.stt_engine_usable.argtypes = [vp]
+    lib.stt_decode_step.restype = i32
+    lib.stt_decode_step.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.stt_engine_probe_kernel.restype = i32
     lib.stt_engine_probe_kernel.argtypes = [vp, i32, i32, vp]
     lib.stt_encode.restype = i32
@@ -285,4 +370,4 @@ def _declare(lib):
 
 
 ENGINE_SYMBOLS = ("stt_engine_create", "stt_engine_destroy", "stt_engine_set_weight",
-                  "stt_engine_finalize", "stt_engine_reserve", "stt_engine_probe_kernel", "stt_encode", "stt_decoder_forward", "stt_generate")
+                  "stt_engine_finalize", "stt_engine_reserve", "stt_engine_usable", "stt_engine_probe_kernel", "stt_decode_step", "stt_encode", "stt_decoder_forward", "stt_generate")

@@ -79,18 +79,29 @@ class _Engine(object):
         with self._guard:
             return self._locks[replica]
 
+    # Up to this many sequences (windows x beams) the engine is sized for the text side's worst
+    # case; beyond it from the calls it has seen (rounded up), because the self-attention cache
+    # grows with sequences x positions: large-v3 needs 73 MB per sequence at 448 positions, i.e.
+    # 37 GB for 512 greedy windows against 11 GB for the 132 positions such a call really uses.
+    WORST_CASE_SEQUENCES = 8
+
     def get(self, batch, beams, text_len, prompt_len, replica=0):
         """Engine `replica` (0 unless a caller pipelines batches over several engines).
 
-        Built once for the text side's worst case - every position of the decoder context and a
-        prompt of half of it plus the task tokens, which is what the reference's long-form loop
-        grows to window by window (models/stt/whisper.py:238-243) - so that neither a longer
-        prompt nor `encoder()` followed by `decoder()` ever changes it.  Only a larger batch or
-        more beams than any call before grows it, through stt_engine_reserve: buffers are
-        re-allocated, the weights stay on the device."""
+        Few sequences (the reference's own way of calling: one window, or one window x a few
+        beams): built once for every position of the decoder context and a prompt of half of it
+        plus the task tokens, which is what the long-form loop grows to window by window
+        (models/stt/whisper.py:238-243) - so neither a longer prompt nor `encoder()` followed by
+        `decoder()` ever re-allocates.  Batched calls: sized from the call, text positions rounded
+        up to 64 and prompt tokens to 8.  Whatever grows later goes through stt_engine_reserve:
+        buffers are re-allocated (the encoded batch is lost), the weights stay on the device."""
         ctx = min(int(self.dims['n_text_ctx']), 512)
-        text_len = min(ctx, max(text_len, ctx))
-        prompt_len = max(prompt_len, min(ctx - 1, ctx // 2 + 3))
+        if batch * beams <= self.WORST_CASE_SEQUENCES:
+            text_len = ctx
+            prompt_len = max(prompt_len, min(ctx - 1, ctx // 2 + 3))
+        else:
+            text_len = min(ctx, (max(text_len, 2) + 63) // 64 * 64)
+            prompt_len = min(text_len - 1, (max(prompt_len, 1) + 7) // 8 * 8)
         eng = self._built.get(replica)
         if eng is None:
             eng = WhisperEngine(self.dims, self.weights, max_batch=batch, max_beams=beams,
@@ -98,7 +109,15 @@ class _Engine(object):
             self._built[replica] = eng
         elif (batch > eng.max_batch or beams > eng.max_beams or text_len > eng.max_text_len
               or prompt_len > eng.max_prompt_len):
-            eng.reserve(batch, beams, text_len, prompt_len)
+            try:
+                eng.reserve(batch, beams, text_len, prompt_len)
+            except Exception:
+                # out of memory: the native engine went back to the capacity that fitted, or
+                # holds no buffers at all - in both cases its encoded batch is gone
+                eng._batch = 0
+                if not eng.usable():
+                    del self._built[replica]
+                raise
         return eng
 
 
@@ -143,7 +162,7 @@ class MI355XRuntime(Runtime):
                  max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
                  num_sentences=1, temperature=None, length_temperature=None, length_power=None,
                  logits_filter=None, early_stopping=True, seed=None, replica=0, on_encoded=None,
-                 return_logits=False, return_state=False, **_ignored):
+                 return_logits=False, return_state=False, **other):
         """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
         arguments (lang, verbose, ...) are ignored, as the reference's runtimes do.
         A `temperature` switches token selection from argmax / top-k to categorical draws, as in
@@ -151,8 +170,13 @@ class MI355XRuntime(Runtime):
         `replica` selects one of several engines built from the same weights and `on_encoded(event)`
         is called once the encoder pass is enqueued (the event completes when it has run): both
         exist so that a caller can decode one batch while another engine encodes the next.
-        `return_logits` (greedy search) fills `InferenceOutput.logits` with the processed scores of
-        every step, [B, steps, V] on the GPU (generation_utils.py:266-268, 297); `return_state` is
+        `return_logits` fills `InferenceOutput.logits` with the processed scores of every step,
+        [B, (num_sentences,) steps, V] on the GPU (generation_utils.py:266-268, 297, 422-428).
+        `logits_filter` may be any callable `f(scores, tokens = ..., state = ..., **kwargs)`: the
+        reference's own Whisper filter runs inside the device loop, anything else (and
+        `return_logits` under beam search) runs the loop in Python, one cached decoder step per token,
+        with the scores as CUDA tensors and the remaining keyword arguments of this call passed on
+        to the filter as the reference does (generation_utils.py:360-366, 518-520).  `return_state` is
         refused: the decoder state is the engine's own K/V cache, which has no meaning outside it."""
         if return_state:
             raise ValueError('return_state: the K/V cache stays inside the engine (call the runtime '
@@ -197,7 +221,8 @@ class MI355XRuntime(Runtime):
                 max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
                 early_stopping=early_stopping, temperature=temperature,
                 length_temperature=length_temperature, length_power=length_power,
-                logits_filter=logits_filter, seed=seed, return_logits=bool(return_logits))
+                logits_filter=logits_filter, seed=seed, return_logits=bool(return_logits),
+                filter_kwargs=other)
         toks, lengths, scores = out[:3]
         return InferenceOutput(tokens=toks, lengths=lengths, scores=scores,
                                logits=out[3] if return_logits else None, state=None, attention_weights=None)
@@ -237,7 +262,8 @@ class MI355XRuntime(Runtime):
                 if not same:
                     raise ValueError('encoder_output is not the (unmodified) tensor the last encoder() call '
                                      'returned: the engine decodes against its own copy of the encoder state')
-                if self._state_owner() is not self:
+                # (growing the engine for a longer token list drops its encoded batch)
+                if self._state_owner() is not self or eng._batch != known[1][0]:
                     eng.encode(known[3])
             self._mark_state_owner()
             return eng.decoder_logits(tokens)
