@@ -201,6 +201,7 @@ int stt_decode_step(stt_engine* engine, const int32_t* d_tokens, int n_seq, int 
  * benchmark can bracket it with events on its own stream (inside stt_generate the kernel runs
  * in a replayed graph on an engine-owned stream).  Results are discarded. */
 #define STT_PROBE_CROSS_ATTENTION 0   /* attn_decoder_cross_kernel of decoder layer `layer` */
+#define STT_PROBE_CROSS_ATTENTION_BEAMS(n) (0x100 | (n))   /* ... with n <= max_beams sequences per window */
 int stt_engine_probe_kernel(stt_engine* engine, int kernel, int layer, void* stream);
 
 #define STT_METHOD_GREEDY 0
@@ -234,6 +235,11 @@ typedef struct {
                                      top-k.  The reported score is the log-probability of the
                                      token drawn */
   uint64_t seed;                  /* of the draws: same seed, same inputs -> same tokens */
+  const int32_t* max_steps_per_window; /* NULL, or host [batch]: window b produces at most that many new tokens
+                                     (>= 1; values above max_steps change nothing) and counts as finished after
+                                     them, as a call of its own with that max_length would end
+                                     (generation_utils.py:794-801): the batched form of the reference's one
+                                     max_length per (single-window) call.  Tokens after the limit are pad_token */
   float* d_logits_out;            /* NULL, or device [batch][max_steps][n_vocab] float32 that receives the
                                      processed scores (log-probabilities after temperature, filter and
                                      log-softmax) of every step: InferenceOutput.logits with

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64) void attn_decoder_self_kernel(const SelfAttnArg
   const int lane = threadIdx.x;
   const int piece = lane & 7, kg = lane >> 3;
   const int h = blockIdx.x, i = blockIdx.y;
+  if (a.finished && a.finished[i]) return;     // block-uniform: the sequence has ended
   const int d_model = a.heads * 64;
   const int base = a.base_len[i];
   const long slot_stride = (long)a.heads * a.max_len * 64;
@@ -385,6 +386,11 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int piece = lane & 7, kg = lane >> 3;
   const int h = blockIdx.x, win = blockIdx.y;
+  if (a.finished) {                            // block-uniform: every sequence of the window has ended
+    int live = 0;
+    for (int sq = 0; sq < a.seq_per_win; ++sq) live |= !a.finished[win * a.seq_per_win + sq];
+    if (!live) return;
+  }
   const int d_model = a.heads * 64;
   const int nq_total = a.seq_per_win * a.s_new;
   const long row0 = (long)win * nq_total;          // first query row of this window

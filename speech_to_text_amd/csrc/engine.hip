@@ -71,7 +71,7 @@ struct stt_engine {
   std::vector<bf16_t*> self_k, self_v;
   int *tokens_in = nullptr, *positions = nullptr;
   GenState gs{};
-  int *d_suppress = nullptr, *d_suppress_first = nullptr;
+  int *d_suppress = nullptr, *d_suppress_first = nullptr, *d_step_cap = nullptr;
   int suppress_cap = 0;
 };
 
@@ -307,9 +307,10 @@ int alloc_buffers(stt_engine* e) {
   g.logits_out = nullptr;
   e->suppress_cap = 4096;
   if ((rc = buf_alloc(e, &e->d_suppress, e->suppress_cap)) ||
-      (rc = buf_alloc(e, &e->d_suppress_first, e->suppress_cap))) return rc;
+      (rc = buf_alloc(e, &e->d_suppress_first, e->suppress_cap)) ||
+      (rc = buf_alloc(e, &e->d_step_cap, B))) return rc;
   // page-locked staging: prompt tokens + positions, suppress lists, results, the "finished" flag
-  e->pinned_ints = 2 * MR + 2 * (size_t)e->suppress_cap + S * L + 2 * S + 64;
+  e->pinned_ints = 2 * MR + 2 * (size_t)e->suppress_cap + S * L + 2 * S + 64 + B;
   STT_HIP_OR_FAIL(hipHostMalloc((void**)&e->pinned, e->pinned_ints * sizeof(int), hipHostMallocDefault), (void)0);
   return STT_OK;
 }
@@ -565,8 +566,11 @@ namespace {
 // One decoder pass over n_seq sequences x s_new new tokens (tokens_in / positions already on the
 // device).  last_only: logits of the last new token of every sequence -> gs.logits [n_seq][V];
 // otherwise logits of every row -> d_all_logits [rows][V].
+// finished: null, or the per-sequence flags of a generation loop: the attention kernels skip
+// sequences (self-attention) and windows (cross-attention) that have ended.
 int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last_only,
-                 float* d_all_logits, hipStream_t st, float* d_last_logits = nullptr) {
+                 float* d_all_logits, hipStream_t st, float* d_last_logits = nullptr,
+                 const int* finished = nullptr) {
   float* last_dst = d_last_logits ? d_last_logits : e->gs.logits;
   const stt_model_config& c = e->cfg;
   const int d = c.n_text_state, H = c.n_text_head, V = c.n_vocab;
@@ -598,14 +602,14 @@ int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last
       dense(e, e->dh, d, L.wqkv, L.bqkv, rows, 3 * d, d, EPI_BF16, e->dqkv, 3 * d, nullptr, st);
     }
     SelfAttnArgs sa{e->dqkv, e->self_k[l], e->self_v[l], e->gs.slot_of, e->gs.base_len, e->datt,
-                    n_seq, s_new, H, e->max_len};
+                    n_seq, s_new, H, e->max_len, finished};
     launch_attn_decoder_self(sa, st);
     dense(e, e->datt, d, L.wo, L.bo, rows, d, d, EPI_RESID_F32, e->dx, d, &pend, st);
     pend_bias = L.bo;
     // decode steps: the query projection is split over K like the residual projections (twice
     // the blocks of an unsplit launch) and the attention kernel sums the slabs as it loads q
     CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[l], e->cross_v[l], e->datt,
-                     n_seq / seq_per_win, seq_per_win, s_new, H, 1500};
+                     n_seq / seq_per_win, seq_per_win, s_new, H, 1500, finished};
     if (fuse) {
       const int sq = pick_split_k(rows, d, d, e->n_cu);
       ln_dense(L.lncg, L.lncb, L.wq_c, nullptr, d, -1, nullptr, d, sq, e->slabs2);
@@ -762,13 +766,16 @@ int stt_engine_probe_kernel(stt_engine* e, int kernel, int layer, void* stream_)
   if (e->enc_batch < 1) return stt_fail(STT_ERR_INVALID_ARGUMENT, "nothing encoded");
   if (layer < 0 || layer >= e->cfg.n_text_layer) return stt_fail(STT_ERR_INVALID_ARGUMENT, "no such layer");
   const int d = e->cfg.n_text_state, H = e->cfg.n_text_head;
-  if (kernel == STT_PROBE_CROSS_ATTENTION) {
-    // exactly the launch of a greedy token step: one new token per window, the query read as
-    // split-K partial sums (whatever the last step left in them: timing only)
-    const int rows = e->enc_batch;
+  if (kernel == STT_PROBE_CROSS_ATTENTION || (kernel & ~0xFF) == 0x100) {
+    // exactly the launch of a token step: one new token per sequence, `per` sequences per window
+    // (1 = greedy, more = beam search), the query read as split-K partial sums (whatever the last
+    // step left in them: timing only)
+    const int per = kernel == STT_PROBE_CROSS_ATTENTION ? 1 : (kernel & 0xFF);
+    if (per < 1 || per > e->max_beams) return stt_fail(STT_ERR_INVALID_ARGUMENT, "%d sequences per window (max %d)", per, e->max_beams);
+    const int rows = e->enc_batch * per;
     const LayerW& L = e->dec[layer];
     CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[layer], e->cross_v[layer], e->datt,
-                     rows, 1, 1, H, 1500};
+                     e->enc_batch, per, 1, H, 1500, nullptr};
     if (rows <= kDecodeRows) {
       ca.q_slabs = e->slabs; ca.n_q_slabs = pick_split_k(rows, d, d, e->n_cu);
       ca.q_slab_stride = (long)rows * d; ca.q_bias = L.bq_c;
@@ -809,6 +816,18 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
     return stt_fail(STT_ERR_UNSUPPORTED, "d_logits_out (return_logits) is implemented for greedy search only");
   GenState gs = e->gs;
   gs.logits_out = p->d_logits_out;
+  gs.step_cap = nullptr;
+  if (p->max_steps_per_window) {
+    for (int b = 0; b < batch; ++b)
+      if (p->max_steps_per_window[b] < 1)
+        return stt_fail(STT_ERR_INVALID_ARGUMENT, "max_steps_per_window[%d] = %d: must be at least 1", b,
+                        p->max_steps_per_window[b]);
+    gs.step_cap = e->d_step_cap;
+  }
+  // Sequences that have ended are skipped by the attention kernels (their cross K/V are the bulk
+  // of a token step's traffic).  Only with early stopping: without it the caller asked for every
+  // step to be computed as if nothing had ended.
+  const int* skip = p->early_stopping ? gs.finished : nullptr;
 
   // The token step is recorded into a graph (every per-token quantity lives in device memory, so
   // the recorded launches are the same for every token) and replayed.  A stream the caller
@@ -839,7 +858,8 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   int* h_sup = h_pos + e->max_rows;
   int* h_sup1 = h_sup + e->suppress_cap;
   int* h_fin = h_sup1 + e->suppress_cap;         // 64 ints
-  int* h_gen = h_fin + 64;                       // results: [max_seq * max_len], [max_seq], [max_seq]
+  int* h_cap = h_fin + 64;                       // [max_batch]
+  int* h_gen = h_cap + e->max_batch;             // results: [max_seq * max_len], [max_seq], [max_seq]
   int* h_len = h_gen + (size_t)e->max_seq * e->max_len;
   float* h_sc = (float*)(h_len + e->max_seq);
   for (int i = 0; i < n_seq; ++i)
@@ -858,6 +878,11 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
     STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_suppress_first, h_sup1, p->n_suppress_first * 4,
                                    hipMemcpyHostToDevice, st), (void)0);
   }
+  if (gs.step_cap) {
+    // greedy: one sequence per window, the limit is read per sequence; beam search reads it per window
+    memcpy(h_cap, p->max_steps_per_window, (size_t)batch * 4);
+    STT_HIP_OR_FAIL(hipMemcpyAsync(e->d_step_cap, h_cap, (size_t)batch * 4, hipMemcpyHostToDevice, st), (void)0);
+  }
   hipLaunchKernelGGL(init_state_kernel, dim3(n_seq), dim3(64), 0, st, gs, n_seq, prompt_len, e->max_len);
   hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, gs.generated, (long)n_seq * max_steps,
                      p->pad_token);
@@ -873,7 +898,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
     else
       launch_greedy_step(gs, f, lp, n_seq, V, max_steps, s_new, p->eos_token, p->pad_token, st);
   };
-  int rc = decoder_pass(e, n_seq, beams, prompt_len, true, nullptr, st);
+  int rc = decoder_pass(e, n_seq, beams, prompt_len, true, nullptr, st, nullptr, skip);
   if (rc) return rc;
   select(prompt_len);
 
@@ -887,8 +912,8 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
   // (a caller's logits buffer would be baked into the recorded launches: plain launches then)
   if (max_steps > 1 && !(no_graph && no_graph[0] == '1') && !p->d_logits_out) {
     char key[320];
-    snprintf(key, sizeof key, "%d/%d/%d/%d/%d|%d/%d/%d|%a/%d/%a/%d/%a|%d/%d/%d/%d/%d|%d/%llu",
-             p->method, batch, beams, nsent, max_steps, p->eos_token, p->pad_token, p->early_stopping,
+    snprintf(key, sizeof key, "%d/%d/%d/%d/%d/%d|%d/%d/%d|%a/%d/%a/%d/%a|%d/%d/%d/%d/%d|%d/%llu",
+             p->method, batch, beams, nsent, max_steps, gs.step_cap ? 1 : 0, p->eos_token, p->pad_token, p->early_stopping,
              p->temperature, p->has_length_temperature, p->length_temperature, p->has_length_power,
              p->length_power, p->n_suppress, p->n_suppress_first, p->timestamp_filter, p->timestamp_begin,
              p->max_initial_timestamp, p->sample ? 1 : 0, (unsigned long long)(p->sample ? p->seed : 0));
@@ -899,7 +924,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
       hipGraph_t graph = nullptr;
       STT_HIP_OR_FAIL(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), (void)0);
       launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
-      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st, nullptr, skip);
       select(1);
       const hipError_t cap = hipStreamEndCapture(st, &graph);
       if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -922,7 +947,7 @@ int stt_generate(stt_engine* e, const stt_generate_params* p, const int32_t* pro
       STT_HIP_OR_FAIL(hipGraphLaunch(step_exec, st), (void)0);
     } else {
       launch_prepare_step(gs, e->tokens_in, e->positions, n_seq, st);
-      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st);
+      rc = decoder_pass(e, n_seq, beams, 1, true, nullptr, st, nullptr, skip);
       if (rc) return rc;
       select(1);
     }

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GenState s, cons
     const int tok = was_finished ? pad : arg;
     if (!was_finished) s.scores[i] += mx - lse;
     const int fin = was_finished || tok == eos;
-    s.finished[i] = fin;
+    // a window's own limit of new tokens: it ends after them as a call with that max_length would
+    // (the token counts, no EOS is added)
+    s.finished[i] = fin || (s.step_cap && t + 1 >= s.step_cap[i]);
     s.lengths[i] += fin ? 0 : 1;
     if (t < max_steps) s.generated[(long)i * max_steps + t] = tok;
     s.next_token[i] = tok;
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void beam_reorder_kernel(const GenState s, int
     tok = fin ? pad : tok;
     fin = fin || tok == eos;
     len += fin ? 0 : 1;
+    if (s.step_cap && t + 1 >= s.step_cap[b]) fin = 1;
     s.scores_tmp[i] = score;
     s.finished_tmp[i] = fin;
     s.lengths_tmp[i] = len;

@@ -109,6 +109,9 @@ struct SelfAttnArgs {
   const int* base_len; // [n_seq]: positions already in the cache before this call
   bf16_t* out;         // [rows][d]
   int n_seq, s_new, heads, max_len;
+  const int* finished; // null, or [n_seq]: a sequence whose flag is set is skipped (nothing appended, its
+                       // output rows left as they are): its next token is the pad token whatever the
+                       // decoder computes (generation_utils.py:234-236)
 };
 // Appends the new k,v at positions base_len[i] .. +s_new-1 of sequence i (writing into slot i)
 // and attends causally over positions 0 .. base_len[i] + j for new token j.
@@ -124,6 +127,8 @@ struct CrossAttnArgs {
   const bf16_t* v;
   bf16_t* out;         // [n_seq * s_new][d]
   int n_win, seq_per_win, s_new, heads, t_enc;
+  const int* finished; // null, or [n_win * seq_per_win]: a window all of whose sequences are finished is
+                       // skipped (its K/V are not read, its output rows left as they are)
 };
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream);
 
@@ -140,6 +145,7 @@ struct GenState {          // all device pointers; n_seq = batch * beams
   int* step;               // [1]
   int* all_finished;       // [1]
   float* logits_out;       // null, or [n_seq][max_steps][V]: the processed scores of every step (greedy)
+  const int* step_cap;     // null, or [batch]: new tokens window b may produce; it counts as finished after them
   // beam search scratch
   float* cand_val;         // [batch][beams]
   int* cand_idx;           // [batch][beams]

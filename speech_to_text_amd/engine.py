@@ -44,7 +44,8 @@ class GenerateParams(C.Structure):
         ("timestamp_filter", C.c_int32), ("suppress_first", C.POINTER(C.c_int32)),
         ("n_suppress_first", C.c_int32), ("timestamp_begin", C.c_int32),
         ("max_initial_timestamp", C.c_int32), ("check_every", C.c_int32),
-        ("sample", C.c_int32), ("seed", C.c_uint64), ("d_logits_out", C.c_void_p),
+        ("sample", C.c_int32), ("seed", C.c_uint64),
+        ("max_steps_per_window", C.POINTER(C.c_int32)), ("d_logits_out", C.c_void_p),
     ]
 
 
@@ -238,7 +239,7 @@ class WhisperEngine(object):
     def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
                  eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
                  length_power=None, logits_filter=None, check_every=8, sample=None, seed=None,
-                 return_logits=False, filter_kwargs=None):
+                 return_logits=False, filter_kwargs=None, max_new_tokens_per_window=None):
         """`temperature` given (and not 0) means, as in the reference (generation_utils.py:538-548),
         that tokens are drawn from the categorical distribution of the processed scores instead of
         taking the argmax / top-k; `sample = False` keeps the rescaling but not the draw.  `seed`
@@ -249,7 +250,10 @@ class WhisperEngine(object):
         -inf.  `logits_filter`: a list of token ids, a TimestampFilter, the reference's Whisper filter
         bound to a model (all three run inside the device loop), or any other callable
         `f(scores, tokens = ..., state = ..., **filter_kwargs)` on CUDA tensors, which - like
-        `return_logits` under beam search - runs the loop in Python over `decode_step` (eager.py)."""
+        `return_logits` under beam search - runs the loop in Python over `decode_step` (eager.py).
+        `max_new_tokens_per_window` [batch]: a window ends after that many new tokens, exactly as a call
+        of its own with that `max_new_tokens` would (device loop only); with early stopping on, windows
+        that have ended - by EOS or by their limit - cost no attention traffic any more."""
         prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
         if prompt.ndim == 1:
             prompt = prompt[None]
@@ -315,6 +319,12 @@ class WhisperEngine(object):
             a = np.ascontiguousarray(np.asarray(logits_filter, dtype=np.int32).reshape(-1))
             keep.append(a)
             p.suppress, p.n_suppress = a.ctypes.data_as(C.POINTER(C.c_int32)), a.size
+        if max_new_tokens_per_window is not None:
+            caps = np.ascontiguousarray(np.asarray(max_new_tokens_per_window, dtype=np.int32).reshape(-1))
+            if caps.size != b:
+                raise ValueError("max_new_tokens_per_window: one value per window")
+            keep.append(caps)
+            p.max_steps_per_window = caps.ctypes.data_as(C.POINTER(C.c_int32))
         tokens = np.empty((b, nsent, p.max_steps), dtype=np.int32)
         lengths = np.empty((b, nsent), dtype=np.int32)
         scores = np.empty((b, nsent), dtype=np.float32)

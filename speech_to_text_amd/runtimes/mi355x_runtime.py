@@ -12,7 +12,7 @@ through ``BaseModel(runtime = ...)`` (models/interfaces/base_model.py:179-189, 3
   (whisper.py:174-186).
 
 ``path`` is a directory or file holding the weights: ``*.safetensors`` / ``*.pt`` / ``*.npz`` with
-OpenAI or Hugging Face Whisper names, or the string ``random:<size>[:seed]`` for seeded
+OpenAI or Hugging Face Whisper names, or the string ``random:<size>[:seed[:plain|peaked]]`` for seeded
 synthetic weights (no checkpoint can be downloaded offline).
 """
 import collections
@@ -139,7 +139,7 @@ class MI355XRuntime(Runtime):
             parts = path.split(':')
             dims = whisper_dims(parts[1])
             seed = int(parts[2]) if len(parts) > 2 else 0
-            weights = W.random_whisper_weights(dims, seed)
+            weights = W.random_whisper_weights(dims, seed, style=parts[3] if len(parts) > 3 else "plain")
         else:
             weights = _load_state_dict(path)
             dims = W.dims_from_openai_state_dict(weights)

@@ -15,7 +15,15 @@ import numpy as np
 import torch
 
 
-def random_whisper_weights(dims, seed=0):
+def random_whisper_weights(dims, seed=0, style="plain"):
+    """style "plain": unit-scale draws; a greedy decode over them repeats the last prompt token
+    whatever the audio (the tied embedding dominates its own logit).  style "peaked": the same
+    draws rescaled (small embedding and positions, final LayerNorm gain 6, query matrices x 4,
+    decoder attention outputs x 2, rows of the second MLP matrices centred) so that the next token
+    depends on the audio and on the history - what a benchmark's self-check or a generation test
+    needs."""
+    if style not in ("plain", "peaked"):
+        raise ValueError("unknown style %r" % (style,))
     g = torch.Generator().manual_seed(seed)
     w = {}
 
@@ -52,6 +60,20 @@ def random_whisper_weights(dims, seed=0):
         ln(p + "mlp_ln", d)
         lin(p + "mlp.0", 4 * d, d); lin(p + "mlp.2", d, 4 * d, scale=0.5)
     ln("decoder.ln", d)
+    if style == "peaked":
+        for k in w:
+            if k == "decoder.token_embedding.weight":
+                w[k] = w[k] * (0.05 / 0.3)
+            elif k == "decoder.positional_embedding":
+                w[k] = w[k] * 0.5
+            elif k == "decoder.ln.weight":
+                w[k] = w[k] * 6.0
+            elif k.endswith("query.weight"):
+                w[k] = w[k] * 4.0
+            elif k.startswith("decoder.") and k.endswith("attn.out.weight"):
+                w[k] = w[k] * 2.0
+            elif k.endswith("mlp.2.weight"):
+                w[k] = w[k] - w[k].mean(dim=1, keepdim=True)
     return w
 
 

@@ -15,12 +15,49 @@ error of 0.02 std (the stated tolerance) on each of two candidates moves their g
 0.04 std; a lead smaller than that cannot be called either way.  On these weights that is
 0.14 (V = 1000 test model) to 0.43 nats (large-v3 width) against a median lead of 1.4 - 2 nats.
 """
+import json
+import os
+
 import numpy as np
 import torch
 
 from oracle import model as om
 
 MARGIN_REL = 0.04
+
+
+# Measured "engine token == oracle argmax" counts per test, committed next to the fixtures.  A GPU
+# run checks each count against the committed one (one step of slack: a change of rounding order
+# may move a single near-tie) and writes what it measured to gpurun_out/token_parity_measured.json,
+# which is copied over the committed file when a kernel change moves a count on purpose.
+_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "token_parity.json")
+_MEASURED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out",
+                         "token_parity_measured.json")
+
+
+def record_exact(name, exact, total):
+    """Asserts that `exact` of `total` steps is no worse than the committed measurement minus one
+    (or, for a test without a committed entry yet, at least 90 % of the steps) and records it."""
+    known = {}
+    if os.path.exists(_RECORD):
+        with open(_RECORD) as f:
+            known = json.load(f)
+    if name in known and known[name]["total"] == total:
+        assert exact >= known[name]["exact"] - 1, "%s: %d of %d steps equal the oracle's argmax, %d were recorded" % (
+            name, exact, total, known[name]["exact"])
+    else:
+        assert exact >= 0.9 * total, (name, exact, total)
+    measured = {}
+    try:
+        if os.path.exists(_MEASURED):
+            with open(_MEASURED) as f:
+                measured = json.load(f)
+        measured[name] = {"exact": int(exact), "total": int(total)}
+        os.makedirs(os.path.dirname(_MEASURED), exist_ok=True)
+        with open(_MEASURED, "w") as f:
+            json.dump(measured, f, indent=1, sort_keys=True)
+    except OSError:
+        pass                                     # read-only tree: the assertion above is what counts
 
 
 def row_margin(logits_row):

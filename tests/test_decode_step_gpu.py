@@ -221,3 +221,49 @@ def test_smaller_batch_after_non_finite_window(small):
     assert np.isfinite(got).all()
     clean = engine.encode(mel[:2], return_output=True).cpu().numpy()
     assert np.array_equal(got, clean)
+
+
+def test_per_window_token_limits_equal_separate_calls(small):
+    """`max_new_tokens_per_window`: a window ends after its own number of new tokens exactly as a call
+    of its own with that max_new_tokens does (same ids, lengths and scores; pad afterwards), for
+    greedy and for beam search; and with early stopping on, where ended windows are skipped by the
+    attention kernels, the windows still running are not disturbed."""
+    dims, engine, oracle, mel, enc = small
+    engine.encode(mel)
+    caps = [5, 12, 9]
+    kw = dict(eos_token=EOS, pad_token=PAD)
+    free = engine.generate(PROMPT, max_new_tokens=12, early_stopping=False, **kw)
+    for early in (False, True):
+        tok, lens, sc = engine.generate(PROMPT, max_new_tokens=12, early_stopping=early,
+                                        max_new_tokens_per_window=caps, **kw)
+        for i, c in enumerate(caps):
+            assert np.array_equal(tok[i, :c], free[0][i, :c]) and (tok[i, c:] == PAD).all(), (early, i)
+            assert lens[i] == c
+            alone = engine.generate(PROMPT, max_new_tokens=c, early_stopping=False, **kw)
+            assert np.array_equal(alone[0][i], tok[i, :c]) and alone[2][i] == sc[i], (early, i)
+    bkw = dict(method="beam", num_beams=3, num_sentences=3, **kw)
+    tok, lens, sc = engine.generate(PROMPT, max_new_tokens=12, early_stopping=True,
+                                    max_new_tokens_per_window=caps, **bkw)
+    for i, c in enumerate(caps):
+        alone = engine.generate(PROMPT, max_new_tokens=c, early_stopping=False, **bkw)
+        assert np.array_equal(alone[0][i], tok[i, :, :c]) and (tok[i, :, c:] == PAD).all(), i
+        assert np.array_equal(alone[1][i], lens[i]) and np.array_equal(alone[2][i], sc[i]), i
+
+
+def test_ended_windows_are_skipped_without_changing_results(small):
+    """Mixed lengths through a real EOS: window 0 ends at its 4th token, the others run on.  With early
+    stopping on the attention kernels skip window 0 from then on; ids, lengths and scores of every
+    window equal those of the run that computes everything (early stopping off) up to the step
+    at which the last window ends."""
+    dims, engine, oracle, mel, enc = small
+    engine.encode(mel)
+    free, _, _ = engine.generate(PROMPT, max_new_tokens=16, eos_token=EOS, pad_token=PAD, early_stopping=False)
+    others = set(free[1].tolist()) | set(free[2].tolist())
+    at = next(j for j in range(2, 12) if int(free[0, j]) not in others and int(free[0, j]) not in free[0, :j].tolist())
+    eos = int(free[0, at])
+    full = engine.generate(PROMPT, max_new_tokens=16, eos_token=eos, pad_token=PAD, early_stopping=False)
+    skip = engine.generate(PROMPT, max_new_tokens=16, eos_token=eos, pad_token=PAD, early_stopping=True,
+                           check_every=5)
+    assert full[1].tolist() == [at, 16, 16]
+    for a, b in zip(full, skip):
+        assert np.array_equal(a, b)

@@ -151,6 +151,7 @@ def test_greedy_tokens(small):
         # every step: the oracle's argmax, or within the near-tie allowance of it (asserted inside)
         exact, total = P.check_greedy_steps(oracle, enc, prompt, tokens, 999, 999, scores=scores)
     assert total == 60
+    P.record_exact("small_greedy_tokens", exact, total)
     assert len(set(tokens.reshape(-1).tolist())) > 6      # the decode is not a degenerate repeat
     if exact == total:                                    # no near-tie met: the free-running decodes agree
         assert np.array_equal(tokens, ref["tokens"].numpy())
