@@ -23,3 +23,15 @@ for it in range(2):
     print(f'{name} B={B} beam 5 + timestamp filter: encode {1e3*(t1-t0):.1f} ms, {steps} tokens {1e3*(t2-t1):.1f} ms '
           f'({1e3*(t2-t1)/steps:.2f} ms/token), audio-s/s {B*30/(t2-t0):.0f}', flush=True)
 print(toks.shape, lens[:4].ravel())
+# the cross-attention launch of a beam token step on its own (HIP events around single launches)
+L = dims['n_text_layer']
+evs = []
+for it in range(3 * L):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); eng.probe_kernel(0x100 | 5, it % L); b.record()
+    evs.append((a, b))
+torch.cuda.synchronize()
+us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in evs[L:]]))
+gb = B * 2 * 1500 * dims['n_text_state'] * 2 / 1e9
+print(f'cross-attention, 5 queries per window, {B} windows: {us:.1f} us per launch for {gb:.3f} GB = {gb / us * 1e3:.2f} TB/s '
+      f'({"VALU kernel" if os.environ.get("STT_MI355X_CROSS_VALU") else "matrix-core kernel"})', flush=True)

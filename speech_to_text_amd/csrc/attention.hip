@@ -2,6 +2,8 @@
 //
 // Reference semantics (architectures/layers/residual_multi_head_attention.py:167-208):
 // softmax(q k^T / sqrt(64), where(mask, ., -inf)) v, computed per head.
+#include <cstdlib>
+
 #include "kernels.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
@@ -548,9 +550,202 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decoder cross-attention for several queries per window (beam search: beams x new tokens <= 16)
+// on the matrix cores.  The one-query kernel above is a pure stream; with several queries its
+// per-(key, query) dot products, lane sums and exponentials are vector work that caps it near
+// 4 TB/s.  Here a block = (head, window) still reads the window's K and V once; its four waves
+// take 32-key tiles round robin and each keeps a flash-style running softmax of its own keys:
+//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K tile (rows = keys, straight from global memory
+//                 in the operand layout: lane = key row, 16 bytes of its features), B = Q^T (the
+//                 window's queries padded to 16 columns, scaled by log2(e) / 8, rounded to bf16).
+//                 A lane then holds query (lane % 16) against 8 keys.  The two products of a tile
+//                 take the keys 8a + b and 8a + 4 + b (a, b < 4), so that registers j = 0..7 of
+//                 lane group g = lane / 16 are the keys 8g + j in order:
+//   O^T += V^T P^T  exactly the k order of the B operand P^T (the exponentiated scores, rounded to
+//                 bf16, never leave their registers).  A = V^T: the V tile goes through a
+//                 wave-private LDS image [32 keys][64 features] (144-byte rows) as it comes from
+//                 memory and is read back transposed by ds_read_b64_tr_b16.
+// All statistics of a query (maximum, sum, rescale factor) live in the lanes of its column, so the
+// running rescale is lane-local; only the tile maximum crosses lanes (two shuffles).  The four
+// waves' partial (maximum, sum, O^T) are merged through LDS at the end.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float cm_f4;
+typedef __attribute__((ext_vector_type(4))) short cm_s4;
+#define CM_ROW 144                       // bytes per key row of the V image (128 + 16: spreads the banks)
+#define CM_BUF (32 * CM_ROW)
+
+__global__ __launch_bounds__(256) void attn_decoder_cross_mfma_kernel(const CrossAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2 * CM_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, win = blockIdx.y;
+  if (a.finished) {                            // block-uniform: every sequence of the window has ended
+    int live = 0;
+    for (int sq = 0; sq < a.seq_per_win; ++sq) live |= !a.finished[win * a.seq_per_win + sq];
+    if (!live) return;
+  }
+  const int d_model = a.heads * 64;
+  const int nq = a.seq_per_win * a.s_new;          // <= 16
+  const long row0 = (long)win * nq;
+  const int T = a.t_enc;
+  const bf16_t* kb = a.k + ((long)win * a.heads + h) * T * 64;
+  const bf16_t* vb = a.v + ((long)win * a.heads + h) * T * 64;
+  unsigned char* my = lds[wave];
+
+  // B operand Q^T: column = query `col`, k = features 32 c + 8 g .. + 7
+  bf8_t qf[2];
+  {
+    const float scale = 0.125f * 1.4426950408889634f;
+    float qv[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[c][e] = 0.f;
+    if (col < nq) {
+      const long at = (row0 + col) * d_model + h * 64 + 8 * g;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (a.q_slabs) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[c][e] = a.q_bias ? a.q_bias[h * 64 + 32 * c + 8 * g + e] : 0.f;
+          for (int sl = 0; sl < a.n_q_slabs; ++sl) {
+            const cm_f4 lo = *(const cm_f4*)(a.q_slabs + sl * a.q_slab_stride + at + 32 * c);
+            const cm_f4 hi = *(const cm_f4*)(a.q_slabs + sl * a.q_slab_stride + at + 32 * c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qv[c][e] += lo[e]; qv[c][4 + e] += hi[e]; }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[c][e] = bf2f(a.q[at + 32 * c + e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 u;
+      u.x = pack2(qv[c][0] * scale, qv[c][1] * scale); u.y = pack2(qv[c][2] * scale, qv[c][3] * scale);
+      u.z = pack2(qv[c][4] * scale, qv[c][5] * scale); u.w = pack2(qv[c][6] * scale, qv[c][7] * scale);
+      qf[c] = __builtin_bit_cast(bf8_t, u);
+    }
+  }
+
+  const int n_tiles = (T + 31) / 32;
+  // A operand rows of the two score products: keys 8 (col / 4) + col % 4 and that + 4
+  const int krow = 8 * (col >> 2) + (col & 3);
+  auto load_tile = [&](int tile, uint4 (&kk)[4], uint4 (&vv)[4]) {
+    const int k0 = tile * 32;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      int key = k0 + krow + 4 * half;
+      key = key < T ? key : T - 1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        kk[half * 2 + c] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const cross_u4*)(kb + (long)key * 64 + 32 * c + 8 * g)));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = lane + 64 * i;                 // 16-byte piece of the 4 KB tile
+      int key = k0 + (ci >> 3);
+      key = key < T ? key : T - 1;
+      vv[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const cross_u4*)(vb + (long)key * 64 + 8 * (ci & 7))));
+    }
+  };
+
+  cm_f4 o[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) o[nt] = cm_f4{0.f, 0.f, 0.f, 0.f};
+  float m = -__builtin_inff(), lsum = 0.f;
+  uint4 kn[4], vn[4];
+  if (wave < n_tiles) load_tile(wave, kn, vn);
+  int buf = 0;
+  for (int tile = wave; tile < n_tiles; tile += 4) {
+    uint4 kc[4], vc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { kc[i] = kn[i]; vc[i] = vn[i]; }
+    if (tile + 4 < n_tiles) load_tile(tile + 4, kn, vn);
+    unsigned char* img = my + buf * CM_BUF;
+    buf ^= 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = lane + 64 * i;
+      *(uint4*)(img + (ci >> 3) * CM_ROW + (ci & 7) * 16) = vc[i];
+    }
+    // scores, base-2 units: registers r of s1 / s2 are keys k0 + 8 g + r and k0 + 8 g + 4 + r
+    cm_f4 s1 = cm_f4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[0]), qf[0], s1, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[1]), qf[1], s1, 0, 0, 0);
+    s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[2]), qf[0], s2, 0, 0, 0);
+    s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[3]), qf[1], s2, 0, 0, 0);
+    const int kfirst = tile * 32 + 8 * g;
+    if (tile * 32 + 32 > T) {                       // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kfirst + r >= T) s1[r] = -__builtin_inff();
+        if (kfirst + 4 + r >= T) s2[r] = -__builtin_inff();
+      }
+    }
+    float tm = fmaxf(fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])), fmaxf(fmaxf(s2[0], s2[1]), fmaxf(s2[2], s2[3])));
+    tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float mn = fmaxf(m, tm);                  // finite: every tile holds at least one key
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    float p[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(s1[r] - mn); p[4 + r] = __builtin_amdgcn_exp2f(s2[r] - mn); }
+    lsum = lsum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+    uint4 pu;
+    pu.x = pack2(p[0], p[1]); pu.y = pack2(p[2], p[3]); pu.z = pack2(p[4], p[5]); pu.w = pack2(p[6], p[7]);
+    const bf8_t pf = __builtin_bit_cast(bf8_t, pu);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      // transposed read: lane 4 q + p of a 16-lane group addresses key row 8 g + 4 half + q, features
+      // 16 nt + 4 p ..; lane i receives feature 16 nt + i of the four keys
+      const unsigned char* at = img + (8 * g + (col >> 2)) * CM_ROW + (16 * nt + 4 * (col & 3)) * 2;
+      const cm_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cm_s4*)at);
+      const cm_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cm_s4*)(at + 4 * CM_ROW));
+      uint4 vu;
+      const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      vu.x = l2.x; vu.y = l2.y; vu.z = h2.x; vu.w = h2.y;
+      o[nt] = o[nt] * alpha;
+      o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, vu), pf, o[nt], 0, 0, 0);
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  // merge the waves: red[feature][query] of this wave in its own (now idle) LDS region
+  float* red = (float*)my;                           // [64][16] floats = 4 KB, then m[16], l[16]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(16 * nt + 4 * g + r) * 16 + col] = o[nt][r];
+  if (g == 0) { red[1024 + col] = m; red[1040 + col] = lsum; }
+  __syncthreads();
+  for (int e = tid; e < nq * 64; e += 256) {
+    const int qi = e >> 6, d = e & 63;
+    float mw[4], mx = -__builtin_inff();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = ((const float*)lds[w])[1024 + qi]; mx = fmaxf(mx, mw[w]); }
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __builtin_amdgcn_exp2f(mw[w] - mx);
+      num += f * ((const float*)lds[w])[d * 16 + qi];
+      den += f * ((const float*)lds[w])[1040 + qi];
+    }
+    a.out[(row0 + qi) * d_model + h * 64 + d] = f2bf(num / den);
+  }
+}
+
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream) {
   const int nq = a.seq_per_win * a.s_new;
   const dim3 grid(a.heads, a.n_win);
+  static const bool no_mfma = getenv("STT_MI355X_CROSS_VALU") != nullptr;      // A/B and test hook
+  if (nq >= 3 && nq <= 16 && !no_mfma) {
+    hipLaunchKernelGGL(attn_decoder_cross_mfma_kernel, grid, dim3(256), 0, stream, a);
+    return;
+  }
   if (a.heads * a.n_win <= 96 && nq <= 2) {          // a few windows: sixteen waves per block
     if (nq == 1) hipLaunchKernelGGL((attn_decoder_cross_kernel<1, 16>), grid, dim3(1024), 0, stream, a);
     else hipLaunchKernelGGL((attn_decoder_cross_kernel<2, 16>), grid, dim3(1024), 0, stream, a);
