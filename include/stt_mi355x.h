@@ -76,6 +76,7 @@ int stt_logmel_run_static(const stt_logmel_plan* plan, const float* d_pcm, int64
  * reading a file and the mel, utils/audio/audio_io.py:249-264) ---- */
 #define STT_PCM_F32 0
 #define STT_PCM_I16 1
+#define STT_PCM_F64 2
 
 /* Bytes of device workspace stt_pcm_normalize needs (8-byte aligned). */
 size_t stt_pcm_workspace_bytes(void);
@@ -84,7 +85,10 @@ size_t stt_pcm_workspace_bytes(void);
  * float32((d_in[i] - mean) * (1 / max|d_in - mean|)), the clip unchanged apart from the mean when
  * it is flat (peak <= 1e-9).  d_in: n samples of `dtype` (STT_PCM_I16: what wavfile.read / ffmpeg
  * s16le give; reduced and scaled in float64 as numpy does, result bit-identical to the host
- * function.  STT_PCM_F32: float32 arithmetic as numpy's, the mean summed in float64). */
+ * function.  STT_PCM_F32: float32 arithmetic as numpy's, the mean summed in float64.  STT_PCM_F64:
+ * what a resampled clip is (scipy.signal.resample returns float64, audio_processing.py:27-32):
+ * mean, peak and scaling in float64, one rounding to float32 at the end, as numpy does; only the
+ * order of the mean's additions differs from the host's). */
 int stt_pcm_normalize(const void* d_in, int dtype, int64_t n, float* d_out, void* d_workspace,
                       size_t workspace_bytes, void* stream);
 

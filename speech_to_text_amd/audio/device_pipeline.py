@@ -13,7 +13,10 @@ page-locked buffer) and never comes back.
               (clip / 10 ms) flags on the host with the same code as the host path, the kept
               stretches concatenated on the device
 
-Results equal `audio_processing.read_audio` (tests/test_device_pipeline_gpu.py).
+Exactness per path (tests/test_device_pipeline_gpu.py): an int16 clip at the target rate comes out
+bit-identical to the host's `read_audio`; a resampled clip is float64 up to the final cast on both
+sides and differs from the host's by the rounding of the FFT library and of the mean's summation
+order (a few float32 ulps; the reference's own `audio_resample.npy` fixture is met to 1e-6).
 """
 import ctypes as C
 import shutil
@@ -103,13 +106,16 @@ class DeviceAudioPipeline(object):
 
     # -- steps ------------------------------------------------------------------------------
     def normalize(self, x):
-        """normalize_audio(x, max_val = 1.) for an int16 or float32 device tensor."""
-        if x.dtype not in (torch.int16, torch.float32):
+        """normalize_audio(x, max_val = 1.) for an int16, float32 or float64 device tensor, each in the
+        arithmetic numpy uses for that type (a resampled clip is float64 and stays so up to the final
+        cast, utils/audio/audio_io.py:249-256)."""
+        if x.dtype not in (torch.int16, torch.float32, torch.float64):
             x = x.to(torch.float32)
         x = x.contiguous()
         out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        code = {torch.float32: 0, torch.int16: 1, torch.float64: 2}[x.dtype]
         _lib.check(self._lib.stt_pcm_normalize(
-            C.c_void_p(x.data_ptr()), 1 if x.dtype == torch.int16 else 0, x.shape[0], C.c_void_p(out.data_ptr()),
+            C.c_void_p(x.data_ptr()), code, x.shape[0], C.c_void_p(out.data_ptr()),
             C.c_void_p(self._ws.data_ptr()), self._ws.numel(), self._stream()))
         return out
 
@@ -158,7 +164,7 @@ class DeviceAudioPipeline(object):
                 if normalize is not True:
                     x = x.to(torch.float32)
             if normalize is True:
-                x = self.normalize(x if x.dtype != torch.float64 else x.to(torch.float32))
+                x = self.normalize(x)
             elif normalize and normalize > 1 and x.dtype == torch.int16:
                 x = (x.to(torch.float64) / normalize).to(torch.float32)
             elif x.dtype != torch.float32:

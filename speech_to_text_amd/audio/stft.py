@@ -6,7 +6,6 @@ Same constructor arguments, ``__call__`` contract (1-D or [1, n] audio in, a
 torch is only used to own device memory and the stream.
 """
 import json
-import math
 import os
 import threading
 
@@ -17,59 +16,67 @@ from .. import _lib
 from .mel_basis import hann_window, mel_filterbank
 
 
+def _in_samples(value, sampling_rate):
+    """Window / hop / filter lengths may be given in samples (> 1) or as a fraction of a second."""
+    return int(value * sampling_rate) if value <= 1. else value
+
+
 class MelSTFT(object):
-    """Configuration holder with the reference's attribute names (stft.py:23-75)."""
+    """What a mel frontend is configured with, under the attribute and file-key names of the
+    reference's class of the same name (utils/audio/stft.py:23-75, 146-182), so that a `mel_fn.json`
+    it saved builds the same object here and the other way round.  No arithmetic lives here: the
+    subclass with a kernel behind it is `WhisperSTFT`."""
+
+    # file keys, in the order they are written; each is also the attribute that holds the value
+    _FIELDS = ('n_mel_channels', 'sampling_rate', 'win_length', 'hop_length', 'filter_length',
+               'mel_fmin', 'mel_fmax', 'pre_emph', 'normalize_mode')
+    _registry = {}
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        MelSTFT._registry[cls.__name__] = cls
 
     def __init__(self, sampling_rate, n_mel_channels=80, *, win_length=1024, hop_length=256,
                  filter_length=1024, mel_fmin=0.0, mel_fmax=8000.0, normalize_mode=None,
                  pre_emph=0., **kwargs):
-        assert normalize_mode in (None, 'per_feature', 'all_feature')
-        self.n_mel_channels = n_mel_channels
-        self.sampling_rate = sampling_rate
-        self.win_length = win_length if win_length > 1. else int(win_length * sampling_rate)
-        self.hop_length = hop_length if hop_length > 1. else int(hop_length * sampling_rate)
-        self.filter_length = filter_length if filter_length > 1. else int(filter_length * sampling_rate)
-        self.mel_fmin = mel_fmin
-        self.mel_fmax = mel_fmax
-        self.pre_emph = pre_emph
-        self.normalize_mode = normalize_mode
-        self.mel_basis = np.expand_dims(mel_filterbank(
-            self.sampling_rate, self.filter_length, self.n_mel_channels, self.mel_fmin, self.mel_fmax
-        ), axis=0)
+        if normalize_mode not in (None, 'per_feature', 'all_feature'):
+            raise ValueError("normalize_mode must be None, 'per_feature' or 'all_feature', got {!r}".format(normalize_mode))
+        self.sampling_rate, self.n_mel_channels = sampling_rate, n_mel_channels
+        self.win_length = _in_samples(win_length, sampling_rate)
+        self.hop_length = _in_samples(hop_length, sampling_rate)
+        self.filter_length = _in_samples(filter_length, sampling_rate)
+        self.mel_fmin, self.mel_fmax = mel_fmin, mel_fmax
+        self.pre_emph, self.normalize_mode = pre_emph, normalize_mode
+        # [1, filter_length // 2 + 1, n_mel_channels], the layout the reference keeps its basis in
+        self.mel_basis = mel_filterbank(self.sampling_rate, self.filter_length, self.n_mel_channels,
+                                        self.mel_fmin, self.mel_fmax)[None]
 
-    @property
-    def rate(self):
-        return self.sampling_rate
+    rate = property(lambda self: self.sampling_rate)
 
     def get_mel_length(self, audio_length):
-        return int(math.ceil(max(self.filter_length, audio_length) / self.hop_length))
+        """Frames of a clip of `audio_length` samples, clips shorter than one filter being padded
+        to it (stft.py:122-124)."""
+        return -(-max(audio_length, self.filter_length) // self.hop_length)
 
     def get_audio_length(self, mel_length):
-        return mel_length * self.hop_length
+        return self.hop_length * mel_length
 
     def get_config(self):
-        return {
-            'class_name': self.__class__.__name__,
-            'n_mel_channels': self.n_mel_channels,
-            'sampling_rate': self.sampling_rate,
-            'win_length': self.win_length,
-            'hop_length': self.hop_length,
-            'filter_length': self.filter_length,
-            'mel_fmin': self.mel_fmin,
-            'mel_fmax': self.mel_fmax,
-            'pre_emph': self.pre_emph,
-            'normalize_mode': self.normalize_mode,
-        }
+        config = {'class_name': type(self).__name__}
+        config.update((key, getattr(self, key)) for key in self._FIELDS)
+        return config
 
     def __eq__(self, other):
-        return isinstance(other, MelSTFT) and self.get_config() == other.get_config()
+        return isinstance(other, MelSTFT) and other.get_config() == self.get_config()
+
+    __hash__ = None
 
     def save(self, filename):
-        if not filename.endswith('.json'):
-            filename += '.json'
-        with open(filename, 'w') as f:
+        """Writes the configuration as JSON (`.json` appended when missing); returns the path."""
+        path = filename if filename.endswith('.json') else filename + '.json'
+        with open(path, 'w') as f:
             json.dump(self.get_config(), f, indent=4)
-        return filename
+        return path
 
     save_to_file = save
 
@@ -79,13 +86,20 @@ class MelSTFT(object):
 
     @staticmethod
     def create(class_name, *args, **kwargs):
-        if class_name in _mel_classes:
-            return _mel_classes[class_name](*args, **kwargs)
-        elif os.path.isfile(class_name):
+        """`create('WhisperSTFT', ...)` builds that class; `create('<file>.json')` builds what the file
+        describes (its `class_name` key names the class, the other keys are constructor arguments)."""
+        known = MelSTFT._registry
+        if class_name in known:
+            return known[class_name](*args, **kwargs)
+        if isinstance(class_name, str) and os.path.isfile(class_name):
             with open(class_name) as f:
-                return MelSTFT.create(**json.load(f))
-        raise ValueError("Unknown Mel STFT class !\n  Accepted : {}\n  Got : {}".format(
-            tuple(_mel_classes.keys()), class_name))
+                stored = json.load(f)
+            return MelSTFT.create(**stored)
+        raise ValueError("unknown mel frontend {!r}: not one of {} and not a configuration file".format(
+            class_name, sorted(known)))
+
+
+MelSTFT._registry['MelSTFT'] = MelSTFT
 
 
 class WhisperSTFT(MelSTFT):
@@ -212,5 +226,3 @@ class WhisperSTFT(MelSTFT):
                 state.data_ptr(), stream))
         return mel
 
-
-_mel_classes = {'MelSTFT': MelSTFT, 'WhisperSTFT': WhisperSTFT}

@@ -575,7 +575,7 @@ typedef __attribute__((ext_vector_type(4))) short cm_s4;
 #define CM_ROW 144                       // bytes per key row of the V image (128 + 16: spreads the banks)
 #define CM_BUF (32 * CM_ROW)
 
-__global__ __launch_bounds__(256) void attn_decoder_cross_mfma_kernel(const CrossAttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const CrossAttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4][2 * CM_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, g = lane >> 4;

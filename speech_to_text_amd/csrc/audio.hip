@@ -175,8 +175,8 @@ int stt_pcm_normalize(const void* d_in, int dtype, int64_t n, float* d_out, void
   hipStream_t stream = (hipStream_t)stream_;
   if (!d_in || !d_out || !d_workspace) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
   if (n <= 0) return stt_fail(STT_ERR_INVALID_ARGUMENT, "empty clip");
-  if (dtype != STT_PCM_F32 && dtype != STT_PCM_I16)
-    return stt_fail(STT_ERR_UNSUPPORTED, "pcm dtype %d: float32 (0) or int16 (1)", dtype);
+  if (dtype != STT_PCM_F32 && dtype != STT_PCM_I16 && dtype != STT_PCM_F64)
+    return stt_fail(STT_ERR_UNSUPPORTED, "pcm dtype %d: float32 (0), int16 (1) or float64 (2)", dtype);
   if (workspace_bytes < sizeof(NormWs))
     return stt_fail(STT_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, sizeof(NormWs));
   if ((uintptr_t)d_workspace & 7) return stt_fail(STT_ERR_INVALID_ARGUMENT, "workspace must be 8-byte aligned");
@@ -190,6 +190,12 @@ int stt_pcm_normalize(const void* d_in, int dtype, int64_t n, float* d_out, void
     hipLaunchKernelGGL(pcm_sum_kernel<int16_t>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws);
     hipLaunchKernelGGL(pcm_peak_kernel<int16_t>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws);
     hipLaunchKernelGGL(pcm_scale_kernel<int16_t>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws, d_out);
+  } else if (dtype == STT_PCM_F64) {
+    // what scipy's resampler hands normalize_audio: every step in float64, one cast at the end
+    const double* x = (const double*)d_in;
+    hipLaunchKernelGGL(pcm_sum_kernel<double>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws);
+    hipLaunchKernelGGL(pcm_peak_kernel<double>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws);
+    hipLaunchKernelGGL(pcm_scale_kernel<double>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws, d_out);
   } else {
     const float* x = (const float*)d_in;
     hipLaunchKernelGGL(pcm_sum_kernel<float>, dim3(grid), dim3(kThreads), 0, stream, x, (long)n, ws);

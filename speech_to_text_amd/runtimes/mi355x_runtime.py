@@ -12,7 +12,8 @@ through ``BaseModel(runtime = ...)`` (models/interfaces/base_model.py:179-189, 3
   (whisper.py:174-186).
 
 ``path`` is a directory or file holding the weights: ``*.safetensors`` / ``*.pt`` / ``*.npz`` with
-OpenAI or Hugging Face Whisper names, or the string ``random:<size>[:seed[:plain|peaked]]`` for seeded
+OpenAI or Hugging Face Whisper names, a model directory the reference wrote (``saving/*.weights.h5``
++ ``saving/config_models.json``, read in-process), or the string ``random:<size>[:seed[:plain|peaked]]`` for seeded
 synthetic weights (no checkpoint can be downloaded offline).
 """
 import collections
@@ -25,6 +26,7 @@ import torch
 from .runtime import Runtime
 from ..engine import WhisperEngine, TimestampFilter, whisper_dims
 from .. import weights as W
+from .. import keras_checkpoint as kc
 
 InferenceOutput = collections.namedtuple(
     "InferenceOutput", ["tokens", "lengths", "scores", "logits", "state", "attention_weights"]
@@ -32,22 +34,33 @@ InferenceOutput = collections.namedtuple(
 
 
 def _load_state_dict(path):
+    return _load_weights(path)[0]
+
+
+def _load_weights(path):
+    """(OpenAI-named tensors, GELU form or None) of a weight file, a plain weight directory, or a
+    model directory written by the reference (pretrained_models/<name>/{config.json, saving/...},
+    models/interfaces/base_model.py:126-136): there the newest `saving/*.weights.h5` is read
+    in-process (keras_checkpoint.py) and `config_models.json` says which GELU the model uses."""
     if os.path.isdir(path):
-        # a plain weight directory, or a model directory written by the reference
-        # (pretrained_models/<name>/{config.json, saving/...}, models/interfaces/base_model.py:126-136)
         for folder in (path, os.path.join(path, 'saving')):
             if not os.path.isdir(folder):
                 continue
             for name in sorted(os.listdir(folder)):
                 if name.endswith(('.safetensors', '.pt', '.pth', '.npz')):
-                    return _load_state_dict(os.path.join(folder, name))
-        keras_ckpt = [n for f in (path, os.path.join(path, 'saving')) if os.path.isdir(f)
-                      for n in os.listdir(f) if n.endswith('.weights.h5')]
-        if keras_ckpt:
-            raise FileNotFoundError(
-                '{} holds a Keras checkpoint ({}) but no converted weights: run `python tools/convert_keras_weights.py '
-                '{}` once where h5py is installed (it writes saving/weights.npz)'.format(path, keras_ckpt[-1], path))
-        raise FileNotFoundError('no weight file (*.safetensors, *.pt, *.npz) in {}'.format(path))
+                    return _load_weights(os.path.join(folder, name))[0], kc.model_config(path)['gelu_tanh']
+        found = kc.load_model_dir(path)
+        if found is None:
+            raise FileNotFoundError('no weight file (*.safetensors, *.pt, *.npz, *.weights.h5) in {}'.format(path))
+        weights, config = found
+        return {k: torch.from_numpy(v) for k, v in weights.items()}, config['gelu_tanh']
+    if path.endswith('.weights.h5'):
+        weights = kc.to_openai(kc.read_vars(path))
+        return {k: torch.from_numpy(v) for k, v in weights.items()}, kc.model_config(os.path.dirname(path))['gelu_tanh']
+    return _load_file(path), None
+
+
+def _load_file(path):
     if path.endswith('.safetensors'):
         from safetensors.torch import load_file
         sd = load_file(path)
@@ -134,15 +147,22 @@ class MI355XRuntime(Runtime):
 
     # -- Runtime interface -------------------------------------------------
     @staticmethod
-    def load_engine(path, *, gelu='tanh', **kwargs):
+    def load_engine(path, *, gelu=None, **kwargs):
+        """`gelu`: 'tanh' or 'erf'; by default what the model directory's `config_models.json` states,
+        else 'tanh' (the form the name 'gelu' resolves to in Keras 3, which the reference runs)."""
         if isinstance(path, str) and path.startswith('random:'):
             parts = path.split(':')
             dims = whisper_dims(parts[1])
             seed = int(parts[2]) if len(parts) > 2 else 0
             weights = W.random_whisper_weights(dims, seed, style=parts[3] if len(parts) > 3 else "plain")
+            stated = None
         else:
-            weights = _load_state_dict(path)
+            weights, stated = _load_weights(path)
             dims = W.dims_from_openai_state_dict(weights)
+        if gelu is None:
+            gelu = 'tanh' if stated in (None, True) else 'erf'
+        elif gelu not in ('tanh', 'erf'):
+            raise ValueError("gelu must be 'tanh' or 'erf', got {!r}".format(gelu))
         return _Engine(dims, weights, gelu_tanh=(gelu == 'tanh'))
 
     def set_tokens(self, sos_token=None, eos_token=None, pad_token=None):

@@ -58,3 +58,21 @@ def test_kept_stretches_rebuild_the_trimmed_clip():
             assert all(0 <= a < b <= n for a, b in keep) and all(keep[i][1] < keep[i + 1][0] for i in range(len(keep) - 1))
             rebuilt = np.concatenate([x[a:b] for a, b in keep]) if keep else x[:0]
             assert np.array_equal(rebuilt, oracle.trim_silence_rms(x, **kw))
+
+
+def test_reference_resample_fixture(golden_dir):
+    """`tests/__reproduction/audio_resample.npy` of the reference = `load_audio(audio_test.wav,
+    rate = 22050)` (tests/test_utils_audio.py:62-64): 16 kHz int16 -> scipy Fourier resampling ->
+    normalize_audio.  The host path reproduces it exactly; the resampler restated on torch.fft
+    (what the device pipeline runs, there through rocFFT) to float32 rounding."""
+    from speech_to_text_amd.audio import audio_processing as host
+    from speech_to_text_amd.audio.device_pipeline import resample_fft
+    from scipy.io import wavfile
+    want = np.load(os.path.join(golden_dir, "audio_resample.npy"))
+    wav = os.path.join(golden_dir, "audio_test.wav")
+    rate, got = host.read_audio(wav, rate=22050, normalize=True)
+    assert rate == 22050 and got.dtype == np.float32 and got.shape == want.shape == (89412,)
+    assert np.array_equal(got, want)
+    _, pcm = wavfile.read(wav)
+    mine = host.normalize_audio(resample_fft(torch.from_numpy(pcm), 89412).numpy(), max_val=1.)
+    assert np.abs(mine - want).max() < 1e-6

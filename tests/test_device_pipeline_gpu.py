@@ -70,6 +70,28 @@ def test_trim_silence_equals_host(pipe, mode):
         assert np.array_equal(got, want), (mode, n, len(got), len(want))
 
 
+def test_reference_resample_fixture_on_the_device(golden_dir):
+    """The reference's own `audio_resample.npy` (its `load_audio(audio_test.wav, rate = 22050)`,
+    tests/test_utils_audio.py:62-64) through the device pipeline: decode, 16 k -> 22.05 k Fourier
+    resampling (rocFFT, float64), float64 normalisation (stt_pcm_normalize, STT_PCM_F64), one cast."""
+    from speech_to_text_amd.audio.device_pipeline import DeviceAudioPipeline
+    want = np.load(os.path.join(golden_dir, "audio_resample.npy"))
+    rate, got = DeviceAudioPipeline(rate=22050)(os.path.join(golden_dir, "audio_test.wav"), normalize=True)
+    assert rate == 22050 and got.dtype == torch.float32 and got.shape[0] == want.shape[0]
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-6
+
+
+def test_float64_normalisation_follows_numpy(pipe):
+    from speech_to_text_amd.audio.audio_processing import normalize_audio
+    x = np.random.default_rng(3).standard_normal(100003) * 1234.5 + 17.0
+    got = pipe.normalize(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = normalize_audio(x, max_val=1.)
+    assert got.dtype == want.dtype == np.float32
+    assert np.abs(got - want).max() <= 6e-8           # one float32 ulp at 1: the mean's summation order
+    flat = np.full(5000, 3.25)
+    assert np.array_equal(pipe.normalize(torch.from_numpy(flat).cuda()).cpu().numpy(), np.zeros(5000, np.float32))
+
+
 def test_resampled_clip_and_wrapper(pipe, tmp_path, golden_dir):
     """A 22.05 kHz file: Fourier resampling on the device (rocFFT through torch.fft, float64) equals
     scipy.signal.resample on the host; and Whisper.get_input(device_pipeline = True) feeds the same

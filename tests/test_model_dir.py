@@ -1,9 +1,12 @@
 """A model directory as the reference writes it (pretrained_models/<name>/saving/{*.weights.h5,
-tokenizer.json, mel_fn.json}, models/interfaces/base_model.py:126-136) read without Keras: the
-converted weights, the reference-format tokenizer file and the mel configuration.  The fixture
-under tests/golden/keras_model_dir is synthetic (tools/convert_keras_weights.py --make-synthetic):
-no real reference checkpoint is available here, so the variable layout is the one the reference's
-layer classes declare, not one read back from a file the reference wrote (parity unpinned)."""
+config_models.json, tokenizer.json, mel_fn.json}, models/interfaces/base_model.py:126-136) read
+in-process, without Keras or h5py: the checkpoint, the serialised model configuration, the
+reference-format tokenizer file and the mel configuration.  The fixture under
+tests/golden/keras_model_dir is synthetic (tools/convert_keras_weights.py --make-synthetic wrote the
+checkpoint through h5py; tests/golden/keras_model_dir_expected.npz is what h5py's own reader makes of
+it): no real reference checkpoint is available here, so the variable layout is the one the
+reference's layer classes declare, not one read back from a file the reference wrote (parity
+unpinned)."""
 import os
 import shutil
 import subprocess
@@ -20,10 +23,20 @@ def model_dir(golden_dir):
     return os.path.join(golden_dir, "keras_model_dir")
 
 
-def test_converted_weights_load_with_openai_names(model_dir):
-    from speech_to_text_amd.runtimes.mi355x_runtime import _load_state_dict
+def test_directory_holds_only_what_the_reference_writes(model_dir):
+    assert sorted(os.listdir(os.path.join(model_dir, "saving"))) == [
+        "ckpt-0001.weights.h5", "config_models.json", "mel_fn.json", "tokenizer.json"]
+
+
+def test_checkpoint_loads_with_openai_names(model_dir, golden_dir):
+    from speech_to_text_amd.runtimes.mi355x_runtime import _load_state_dict, _load_weights
     from speech_to_text_amd import weights as W
     sd = _load_state_dict(model_dir)
+    expected = np.load(os.path.join(golden_dir, "keras_model_dir_expected.npz"))
+    assert sorted(sd) == sorted(expected.files)
+    for k in expected.files:
+        assert np.array_equal(sd[k].numpy(), expected[k]), k
+    assert _load_weights(model_dir)[1] is True               # config_models.json: 'gelu' = the tanh form
     dims = W.dims_from_openai_state_dict(sd)
     assert dims["n_mels"] == 80 and dims["n_audio_state"] == dims["n_text_state"] == 128
     assert dims["n_audio_layer"] == dims["n_text_layer"] == 1 and dims["n_vocab"] == 512 and dims["n_text_ctx"] == 32
@@ -32,12 +45,39 @@ def test_converted_weights_load_with_openai_names(model_dir):
     assert "decoder.blocks.0.cross_attn.key.weight" in sd and "decoder.blocks.0.cross_attn.key.bias" not in sd
 
 
-def test_unconverted_directory_names_the_converter(model_dir, tmp_path):
-    from speech_to_text_amd.runtimes.mi355x_runtime import _load_state_dict
-    os.makedirs(tmp_path / "saving")
-    shutil.copy(os.path.join(model_dir, "saving", "ckpt-0001.weights.h5"), tmp_path / "saving")
-    with pytest.raises(FileNotFoundError, match="convert_keras_weights"):
-        _load_state_dict(str(tmp_path))
+def test_model_configuration_is_read_and_checked(model_dir, tmp_path):
+    """config_models.json: sizes and the GELU form; a size the checkpoint contradicts is an error,
+    an exact-erf activation selects the other kernel form, the newest checkpoint wins."""
+    import json
+    from speech_to_text_amd import keras_checkpoint as kc
+    from speech_to_text_amd.runtimes.mi355x_runtime import MI355XRuntime
+    cfg = kc.model_config(model_dir)
+    assert cfg["gelu_tanh"] is True
+    assert cfg["dims"] == dict(n_mels=80, n_audio_state=128, n_audio_layer=1, n_audio_head=2, n_audio_ctx=1500,
+                               n_vocab=512, n_text_state=128, n_text_layer=1, n_text_head=2, n_text_ctx=32)
+    assert MI355XRuntime.load_engine(model_dir).gelu_tanh is True
+    copy = tmp_path / "model"
+    shutil.copytree(model_dir, copy)
+    path = copy / "saving" / "config_models.json"
+    config = json.load(open(path))
+    config["model"]["config"]["decoder_ffn_activation"] = {"class_name": "gelu", "config": {"approximate": False}}
+    config["model"]["config"]["encoder_ffn_activation"] = "gelu_exact"
+    config["model"]["config"]["encoder_activation"] = "gelu_exact"
+    json.dump(config, open(path, "w"))
+    assert MI355XRuntime.load_engine(str(copy)).gelu_tanh is False
+    assert MI355XRuntime.load_engine(str(copy), gelu="tanh").gelu_tanh is True
+    config["model"]["config"]["decoder_num_layers"] = 3
+    json.dump(config, open(path, "w"))
+    with pytest.raises(ValueError, match="n_text_layer"):
+        MI355XRuntime.load_engine(str(copy))
+    config["model"]["config"]["decoder_num_layers"] = 1
+    config["model"]["config"]["decoder_ffn_activation"] = "relu"
+    json.dump(config, open(path, "w"))
+    with pytest.raises(ValueError, match="GELU"):
+        MI355XRuntime.load_engine(str(copy))
+    shutil.copy(copy / "saving" / "ckpt-0001.weights.h5", copy / "saving" / "ckpt-0003.weights.h5")
+    assert kc.latest_checkpoint(str(copy)).endswith("ckpt-0003.weights.h5")
+    assert kc.load_model_dir(str(tmp_path)) is None
 
 
 @pytest.mark.skipif(not os.path.exists(H5_PYTHON), reason="no interpreter with h5py")
@@ -53,9 +93,15 @@ def test_converter_round_trip(model_dir, tmp_path):
         assert np.array_equal(made[k], truth[k]), k
     out = str(tmp_path / "again.npz")
     subprocess.run([H5_PYTHON, tool, model_dir, "--out", out], check=True, capture_output=True, timeout=120)
-    again, committed = np.load(out), np.load(os.path.join(model_dir, "saving", "weights.npz"))
+    again, committed = np.load(out), np.load(os.path.join(os.path.dirname(model_dir), "keras_model_dir_expected.npz"))
     for k in committed.files:
         assert np.array_equal(again[k], committed[k]), k
+    # the in-process reader on the freshly written file: same arrays as h5py's
+    from speech_to_text_amd import keras_checkpoint as kc
+    mine = kc.to_openai(kc.read_vars(ckpt))
+    assert sorted(mine) == sorted(truth.files)
+    for k in truth.files:
+        assert np.array_equal(mine[k], truth[k]), k
 
 
 def test_reference_tokenizer_file(model_dir):

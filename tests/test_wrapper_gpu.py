@@ -245,3 +245,62 @@ def test_reference_model_directory(golden_dir):
     assert rel_l2(got.numpy(), want.numpy()) < 2e-2
     res = stt.infer(os.path.join(golden_dir, "audio_test.wav"), lang="en", max_length=20)
     assert isinstance(res["segments"][0]["text"], str)
+
+
+def test_translate_task_prompt(model):
+    """`translate(...)` (models/stt/__init__.py:48-51) differs from `transcribe` by the task token of
+    the prompt only (whisper.py:333-338): the runtime is called with [<|sot|>, <|fr|>, <|translate|>]
+    and the ids are the engine's for that prompt, checked step by step against the oracle."""
+    from oracle import model as om
+    from speech_to_text_amd.stt import whisper as W
+    from speech_to_text_amd.weights import random_whisper_weights
+    from tests import _parity as P
+    rng = np.random.default_rng(8)
+    audio = rng.uniform(-1, 1, 16000 * 9).astype(np.float32)
+    kw = dict(max_length=20, normalize=False, trim_silence=False, logits_filter=NO_TIMESTAMPS, early_stopping=False)
+    results = {}
+    inner = model.model
+    for task in ("translate", "transcribe"):
+        calls = []
+        model.model = _recorded(model, calls)
+        try:
+            if task == "translate":
+                res = W.translate(audio, lang="fr", model=model, **kw)
+            else:
+                res = W.transcribe(audio, lang="fr", model=model, **kw)
+        finally:
+            model.model = inner
+        res = res[0] if isinstance(res, list) else res
+        assert len(calls) == 1
+        results[task] = (calls[0], res)
+    v = model.vocabulary
+    assert results["translate"][0][0] == [v.sos_token_idx, v.lang_to_idx["fr"], v.translate_token_idx]
+    assert results["transcribe"][0][0] == [v.sos_token_idx, v.lang_to_idx["fr"], v.transcribe_token_idx]
+    assert v.translate_token_idx != v.transcribe_token_idx
+    prompt, ids = results["translate"][0]
+    assert len(ids) == 20 - 3 and np.array_equal(results["translate"][1]["segments"][0]["tokens"], ids)
+    dims = om.Dims.named("tiny")
+    w = {k: t.to(torch.bfloat16).float() for k, t in random_whisper_weights(model.model.dims, 0).items()}
+    oracle = om.Whisper(dims, w)
+    mel = model.get_input(audio, pad_or_trim=True, normalize=False, trim_silence=False).cpu()[None]
+    with torch.no_grad():
+        P.check_greedy_steps(oracle, oracle.encoder(mel), np.array([prompt]), np.array([ids]), model.eos_token_idx,
+                             model.eos_token_idx, logits_filter=NO_TIMESTAMPS)
+
+
+@pytest.mark.skipif(not os.environ.get("STT_WHISPER_BASE_WEIGHTS"),
+                    reason="set STT_WHISPER_BASE_WEIGHTS to an OpenAI / Hugging Face whisper-base checkpoint")
+def test_notebook_known_answer(golden_dir):
+    """The one known answer the reference holds for the model side of the path (speech_to_text.ipynb,
+    cell 13): whisper-base, lang = 'en', greedy, its `audio_en.wav` (byte-identical to
+    tests/data/audio_test.wav) -> 396 frames, end = 3.96 s and the ids below after the
+    <|notimestamps|> token the model writes itself ("The streets were narrow and unpaid but very
+    fairly clean.").  Needs the real checkpoint, which no offline box has: runs wherever
+    STT_WHISPER_BASE_WEIGHTS points at one, and is the route to pinning oracle/model.py."""
+    from speech_to_text_amd.stt import Whisper
+    stt = Whisper(pretrained="base", path=os.environ["STT_WHISPER_BASE_WEIGHTS"])
+    res = stt.infer(os.path.join(golden_dir, "audio_test.wav"), lang="en")
+    seg = res["segments"][0]
+    assert len(res["segments"]) == 1 and abs(seg["end"] - 3.96) < 1e-9
+    ids = [int(t) for t in seg["tokens"] if t < stt.eos_token_idx]
+    assert ids == [440, 8481, 645, 9432, 293, 517, 35035, 457, 588, 6457, 2541, 13]

@@ -3,11 +3,12 @@
 
 The reference saves its models with `keras.Model.save_weights` into
 `pretrained_models/<name>/saving/ckpt-NNNN.weights.h5` next to `config_models.json`
-(custom_train_objects/checkpoint_manager.py:137-167).  The MI355X runtime reads safetensors /
-npz with OpenAI names; this tool (numpy + h5py only - run it where h5py exists, e.g.
-`/opt/conda/bin/python3.9 tools/convert_keras_weights.py <model dir>`) writes
-`saving/weights.npz` beside the checkpoint so that `MI355XRuntime.load_engine(<model dir>)`
-finds it.  Nothing here needs keras.
+(custom_train_objects/checkpoint_manager.py:137-167).  `MI355XRuntime.load_engine(<model dir>)`
+reads such a directory directly (speech_to_text_amd/keras_checkpoint.py, own HDF5 reader); this
+tool is the same conversion as a file-to-file step through h5py (run it where h5py exists, e.g.
+`/opt/conda/bin/python3.9 tools/convert_keras_weights.py <model dir>`): it writes
+`saving/weights.npz`, and its `--make-synthetic` writes the test checkpoints.  Nothing here needs
+keras.
 
 A Keras-3 weights file is a tree of groups that follows the attribute names of the model
 (`encoder/transformer_layers/transformer_layer_3/attention/wq/vars/0` ...), every layer's variables
@@ -50,87 +51,8 @@ def read_vars(path):
     return found
 
 
-_INDEX = re.compile(r"(?:transformer_layer|layer)(?:_(\d+))?$")
-
-
-def _role(tokens):
-    """(side, layer index or None, module, part) from the path components of a layer."""
-    side = "decoder" if any("decoder" in t for t in tokens) else "encoder" if any("encoder" in t for t in tokens) else None
-    index = None
-    for t in tokens:
-        m = _INDEX.match(t)
-        if m:
-            index = int(m.group(1) or 0)
-    has = lambda *names: any(t in names for t in tokens)
-    if has("enc_attention", "enc_mha"):
-        module = "cross_attn"
-    elif has("attention", "mha"):
-        module = "attn"
-    elif has("ffn"):
-        module = "mlp"
-    else:
-        module = None
-    part = None
-    for names, p in ((("wq", "query_layer"), "query"), (("wk", "key_layer"), "key"), (("wv", "value_layer"), "value"),
-                     (("output_layer",), "out"), (("inp_norm_layer", "norm_input"), "ln")):
-        if tokens[-1] in names:
-            part = p
-    return side, index, module, part
-
-
-def to_openai(layers):
-    """Layer variables keyed by group path -> {OpenAI name: array in OpenAI layout}."""
-    out, conv, tables = {}, [], []
-    for path, arrays in sorted(layers.items()):
-        tokens = path.lower().split("/")
-        if tokens[0] == "optimizer":
-            continue
-        side, index, module, part = _role(tokens)
-        first = arrays[0]
-        if first.ndim == 3:                                    # Conv1D kernel [k, in, out] (+ bias)
-            conv.append((path, arrays))
-            continue
-        if side is None:
-            raise ValueError("cannot tell encoder from decoder for %r" % path)
-        if index is None:
-            if first.ndim == 2 and len(arrays) == 1:           # embedding tables
-                tables.append(first)
-            elif first.ndim == 1 and len(arrays) == 2:         # the block's final LayerNorm
-                name = "encoder.ln_post" if side == "encoder" else "decoder.ln"
-                out[name + ".weight"], out[name + ".bias"] = arrays
-            else:
-                raise ValueError("unexpected variables at %r: %s" % (path, [a.shape for a in arrays]))
-            continue
-        prefix = "%s.blocks.%d." % (side, index)
-        if module in ("attn", "cross_attn"):
-            if part == "ln":
-                out[prefix + module + "_ln.weight"], out[prefix + module + "_ln.bias"] = arrays
-            elif part in ("query", "key", "value", "out"):
-                out[prefix + "%s.%s.weight" % (module, part)] = np.ascontiguousarray(first.T)
-                if len(arrays) > 1:
-                    out[prefix + "%s.%s.bias" % (module, part)] = arrays[1]
-            else:
-                raise ValueError("unknown attention part at %r" % path)
-        elif module == "mlp":
-            which = "0" if first.shape[1] > first.shape[0] else "2"          # [d, 4d] up, [4d, d] down
-            out[prefix + "mlp.%s.weight" % which] = np.ascontiguousarray(first.T)
-            if len(arrays) > 1:
-                out[prefix + "mlp.%s.bias" % which] = arrays[1]
-        elif first.ndim == 1 and len(arrays) == 2:             # the layer's own `norm` (before the FFN)
-            out[prefix + "mlp_ln.weight"], out[prefix + "mlp_ln.bias"] = arrays
-        else:
-            raise ValueError("unplaced variables at %r: %s" % (path, [a.shape for a in arrays]))
-    if len(conv) != 2:
-        raise ValueError("expected the two Conv1D layers of the stem, found %d" % len(conv))
-    conv.sort(key=lambda pa: (pa[1][0].shape[1] == pa[1][0].shape[2], pa[0]))        # [3, n_mels, d] first
-    for i, (_, arrays) in enumerate(conv, start=1):
-        out["encoder.conv%d.weight" % i] = np.ascontiguousarray(np.transpose(arrays[0], (2, 1, 0)))
-        out["encoder.conv%d.bias" % i] = arrays[1]
-    if len(tables) != 2:
-        raise ValueError("expected token and positional embedding, found %d tables" % len(tables))
-    tables.sort(key=lambda a: -a.shape[0])
-    out["decoder.token_embedding.weight"], out["decoder.positional_embedding"] = tables
-    return {k: np.asarray(v, dtype=np.float32) for k, v in out.items()}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_to_text_amd.keras_checkpoint import to_openai  # noqa: E402  (numpy only: the mapping the runtime uses)
 
 
 def write_synthetic(path, n_mels=80, d=128, layers=1, vocab=512, ctx=32, seed=0):
