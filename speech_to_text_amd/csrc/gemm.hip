@@ -1156,11 +1156,18 @@ void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* sla
     // All rows in one block (the weights are then read once) unless that leaves fewer blocks than
     // CUs: then the rows per block are halved until the chip is covered.  At 256 rows of
     // large-v3 this took the token step from 13.7 to 12.7 ms (QKV and FC1 had 60 and 80 blocks).
-    constexpr int kFill = 256;
+    static const int kFill = getenv("STT_MI355X_MID_FILL") ? atoi(getenv("STT_MI355X_MID_FILL")) : 256;
+    static const int force_tm = getenv("STT_MI355X_MID_TM") ? atoi(getenv("STT_MI355X_MID_TM")) : 0;
     int tm = (mt + 3) / 4;
     tm = tm > 4 ? 4 : tm;                  // at most 256 rows per block; more rows, more row groups
     const long col_blocks = (g.n + 63) / 64;
     while (tm > 1 && col_blocks * split_k * ((mt + 4 * tm - 1) / (4 * tm)) < kFill) tm = (tm + 1) / 2;
+    // Above 256 rows 128 rows per block are best for every decoder shape of large-v3 (two blocks
+    // share a CU and hide each other's chunk barriers): at 512 rows FC2 22.6 -> 18.7 us (the rule
+    // above picks 256 rows for it), QKV 15.4 -> 14.4 us (64 rows), FC1 and the K = N projections
+    // stay where the rule puts them; 64, 192 and 256 rows per block are slower for all of them.
+    if (mt > 16) tm = 2;
+    if (force_tm >= 1 && force_tm <= 4) tm = force_tm;
     switch (tm) {
       case 1: launch_mid_tm<1>(g, epilogue, split_k, slabs, stream); return;
       case 2: launch_mid_tm<2>(g, epilogue, split_k, slabs, stream); return;
