@@ -75,6 +75,10 @@ def say(msg):
     if os.environ.get("STT_BENCH_VERBOSE"):
         sys.stderr.write("[bench %7.2f s] %s\n" % (time.time() - _T0, msg))
         sys.stderr.flush()
+    if os.environ.get("STT_BENCH_DUMP_MAPS"):        # the address map, to place a fault address afterwards
+        with open("/proc/self/maps") as f, open(os.environ["STT_BENCH_DUMP_MAPS"], "w") as out:
+            out.write("# %s\n" % msg)
+            out.write(f.read())
 
 
 # ------------------------------------------------------------------------------ launching
@@ -646,9 +650,16 @@ def bench_beam(args, dims, weights, fn, pcm, n_w, beams=5):
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": k_bytes, "windows_per_launch": n_w},
+           "note_traffic": None,
            "note": "whisper-%s beam search, %d beams, timestamp rules, %d windows per engine call (log-mel + "
                    "encoder + %d tokens), this rank alone (BASELINE.json configs[4])"
                    % (args.model, beams, n_w, args.new_tokens)}
+    if dims["n_text_state"] == 1280 and beams == 5:
+        t = measured_traffic("beam100_pmc_hbm.csv", "attn_decoder_cross_mfma_kernel")
+        if t is not None:
+            out["roofline"]["traffic"] = int(round(t * n_w / 100.0))
+            out["note_traffic"] = ("separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes measured %d bytes per "
+                                   "100-window launch of this kernel (profiles/, beam100_pmc_hbm.csv)" % t)
     del eng
     return out
 

@@ -28,6 +28,11 @@ eng.encode(mel)
 torch.cuda.synchronize(); say("encoded; generate ...")
 prompt = np.array([[50258, 50259, 50359]] * B, dtype=np.int32)
 eng.generate(prompt, max_new_tokens=T, eos_token=50257, pad_token=50257, early_stopping=False)
-say("generated; destroying the engine ...")
+say("generated (token-step graph recorded and replayed %d times); generate again (cached graph) ..." % (T - 2))
+if os.environ.get("STAGES_ENCODE_BETWEEN"):
+    eng.encode(mel)
+    say("encoded again (enqueued); generate ...")
+eng.generate(prompt, max_new_tokens=T, eos_token=50257, pad_token=50257, early_stopping=False)
+say("generated again; destroying the engine ...")
 del eng
 torch.cuda.synchronize(); say("done")

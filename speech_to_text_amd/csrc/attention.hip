@@ -556,8 +556,10 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
 // per-(key, query) dot products, lane sums and exponentials are vector work that caps it near
 // 4 TB/s.  Here a block = (head, window) still reads the window's K and V once; its four waves
 // take 32-key tiles round robin and each keeps a flash-style running softmax of its own keys:
-//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K tile (rows = keys, straight from global memory
-//                 in the operand layout: lane = key row, 16 bytes of its features), B = Q^T (the
+//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K tile (rows = keys; fetched in whole 1 KiB wave
+//                 accesses into a wave-private LDS image and read back in the operand layout - loading
+//                 the operand layout straight from memory touches sixteen 128-byte lines per quarter
+//                 wave for 16 bytes each, 127 against 1xx us per launch), B = Q^T (the
 //                 window's queries padded to 16 columns, scaled by log2(e) / 8, rounded to bf16).
 //                 A lane then holds query (lane % 16) against 8 keys.  The two products of a tile
 //                 take the keys 8a + b and 8a + 4 + b (a, b < 4), so that registers j = 0..7 of
@@ -575,8 +577,8 @@ typedef __attribute__((ext_vector_type(4))) short cm_s4;
 #define CM_ROW 144                       // bytes per key row of the V image (128 + 16: spreads the banks)
 #define CM_BUF (32 * CM_ROW)
 
-__global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const CrossAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2 * CM_BUF];
+__global__ __launch_bounds__(256, 3) void attn_decoder_cross_mfma_kernel(const CrossAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][2 * CM_BUF];      // per wave: K image | V image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, win = blockIdx.y;
@@ -604,20 +606,37 @@ __global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const C
       for (int e = 0; e < 8; ++e) qv[c][e] = 0.f;
     if (col < nq) {
       const long at = (row0 + col) * d_model + h * 64 + 8 * g;
+      if (a.q_slabs) {
+        // at most 8 slabs: all requested before any is added (a loop of dependent loads would cost a
+        // memory round trip per slab), added in slab order like the one-query kernel does
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (a.q_slabs) {
+        for (int c = 0; c < 2; ++c) {
+          cm_f4 ps[8][2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) qv[c][e] = a.q_bias ? a.q_bias[h * 64 + 32 * c + 8 * g + e] : 0.f;
-          for (int sl = 0; sl < a.n_q_slabs; ++sl) {
-            const cm_f4 lo = *(const cm_f4*)(a.q_slabs + sl * a.q_slab_stride + at + 32 * c);
-            const cm_f4 hi = *(const cm_f4*)(a.q_slabs + sl * a.q_slab_stride + at + 32 * c + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qv[c][e] += lo[e]; qv[c][4 + e] += hi[e]; }
+          for (int sl = 0; sl < 8; ++sl) {
+            const float* src = a.q_slabs + (sl < a.n_q_slabs ? sl : a.n_q_slabs - 1) * a.q_slab_stride + at + 32 * c;
+            ps[sl][0] = *(const cm_f4*)src;
+            ps[sl][1] = *(const cm_f4*)(src + 4);
           }
-        } else {
+          if (a.q_bias) {
+            const cm_f4 b0 = *(const cm_f4*)(a.q_bias + h * 64 + 32 * c + 8 * g), b1 = *(const cm_f4*)(a.q_bias + h * 64 + 32 * c + 8 * g + 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) qv[c][e] = bf2f(a.q[at + 32 * c + e]);
+            for (int e = 0; e < 4; ++e) { qv[c][e] = b0[e]; qv[c][4 + e] = b1[e]; }
+          }
+#pragma unroll
+          for (int sl = 0; sl < 8; ++sl)
+            if (sl < a.n_q_slabs) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { qv[c][e] += ps[sl][0][e]; qv[c][4 + e] += ps[sl][1][e]; }
+            }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint4 raw = *(const uint4*)(a.q + at + 32 * c);
+          const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { qv[c][2 * e] = __uint_as_float(w4[e] << 16); qv[c][2 * e + 1] = __uint_as_float(w4[e] & 0xFFFF0000u); }
         }
       }
     }
@@ -633,21 +652,18 @@ __global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const C
   const int n_tiles = (T + 31) / 32;
   // A operand rows of the two score products: keys 8 (col / 4) + col % 4 and that + 4
   const int krow = 8 * (col >> 2) + (col & 3);
+  unsigned char* kimg = my;
+  unsigned char* img = my + CM_BUF;
+  // Both tiles are fetched as the 4 KB they are in memory (lane -> consecutive 16-byte pieces, 1 KiB
+  // per wave instruction) and land in registers one tile ahead of their use.
   auto load_tile = [&](int tile, uint4 (&kk)[4], uint4 (&vv)[4]) {
     const int k0 = tile * 32;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      int key = k0 + krow + 4 * half;
-      key = key < T ? key : T - 1;
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        kk[half * 2 + c] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const cross_u4*)(kb + (long)key * 64 + 32 * c + 8 * g)));
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = lane + 64 * i;                 // 16-byte piece of the 4 KB tile
       int key = k0 + (ci >> 3);
       key = key < T ? key : T - 1;
+      kk[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const cross_u4*)(kb + (long)key * 64 + 8 * (ci & 7))));
       vv[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const cross_u4*)(vb + (long)key * 64 + 8 * (ci & 7))));
     }
   };
@@ -656,27 +672,28 @@ __global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const C
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) o[nt] = cm_f4{0.f, 0.f, 0.f, 0.f};
   float m = -__builtin_inff(), lsum = 0.f;
-  uint4 kn[4], vn[4];
-  if (wave < n_tiles) load_tile(wave, kn, vn);
-  int buf = 0;
-  for (int tile = wave; tile < n_tiles; tile += 4) {
-    uint4 kc[4], vc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { kc[i] = kn[i]; vc[i] = vn[i]; }
-    if (tile + 4 < n_tiles) load_tile(tile + 4, kn, vn);
-    unsigned char* img = my + buf * CM_BUF;
-    buf ^= 1;
+  // one tile: LDS images, scores, running softmax, O^T += V^T P^T
+  auto process = [&](int tile, const uint4 (&kk)[4], const uint4 (&vv)[4]) {
+    // (the wave's LDS operations execute in order: this tile's writes follow the last tile's reads)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = lane + 64 * i;
-      *(uint4*)(img + (ci >> 3) * CM_ROW + (ci & 7) * 16) = vc[i];
+      *(uint4*)(kimg + (ci >> 3) * CM_ROW + (ci & 7) * 16) = kk[i];
+      *(uint4*)(img + (ci >> 3) * CM_ROW + (ci & 7) * 16) = vv[i];
     }
     // scores, base-2 units: registers r of s1 / s2 are keys k0 + 8 g + r and k0 + 8 g + 4 + r
     cm_f4 s1 = cm_f4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[0]), qf[0], s1, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[1]), qf[1], s1, 0, 0, 0);
-    s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[2]), qf[0], s2, 0, 0, 0);
-    s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, kc[3]), qf[1], s2, 0, 0, 0);
+    {
+      const unsigned char* ka = kimg + krow * CM_ROW + 16 * g;
+      const bf8_t a00 = __builtin_bit_cast(bf8_t, *(const uint4*)(ka));
+      const bf8_t a01 = __builtin_bit_cast(bf8_t, *(const uint4*)(ka + 64));
+      const bf8_t a10 = __builtin_bit_cast(bf8_t, *(const uint4*)(ka + 4 * CM_ROW));
+      const bf8_t a11 = __builtin_bit_cast(bf8_t, *(const uint4*)(ka + 4 * CM_ROW + 64));
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, qf[0], s1, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, qf[1], s1, 0, 0, 0);
+      s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, qf[0], s2, 0, 0, 0);
+      s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, qf[1], s2, 0, 0, 0);
+    }
     const int kfirst = tile * 32 + 8 * g;
     if (tile * 32 + 32 > T) {                       // ragged last tile (wave-uniform)
 #pragma unroll
@@ -711,6 +728,17 @@ __global__ __launch_bounds__(256, 4) void attn_decoder_cross_mfma_kernel(const C
       o[nt] = o[nt] * alpha;
       o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, vu), pf, o[nt], 0, 0, 0);
     }
+  };
+  // Two register sets alternate between "in flight" and "being used", so the loads of a wave's
+  // next tile are outstanding during the whole of the current one (a single set copied at the top
+  // of the loop makes the compiler wait for the new loads before it loops).
+  uint4 ka[4], va[4], kb2[4], vb2[4];
+  if (wave < n_tiles) load_tile(wave, ka, va);
+  for (int tile = wave; tile < n_tiles; tile += 8) {
+    if (tile + 4 < n_tiles) load_tile(tile + 4, kb2, vb2);
+    process(tile, ka, va);
+    if (tile + 8 < n_tiles) load_tile(tile + 8, ka, va);
+    if (tile + 4 < n_tiles) process(tile + 4, kb2, vb2);
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
