@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--windows", type=int, default=1200, help="whisper: 30 s windows in the job (10 h)")
-    ap.add_argument("--batch", type=int, default=512, help="whisper: windows per engine call at most")
+    ap.add_argument("--batch", type=int, default=600, help="whisper: windows per engine call at most")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--logmel-steps", type=int, default=200, help="steps of the log-mel leg of the whisper line (0 = skip)")
     ap.add_argument("--pipelined", type=int, default=1, help="whisper: also measure two engines per GPU, one phase apart")
@@ -400,16 +400,12 @@ def bench_whisper(args, rank, world):
             return engine.generate(prompt, max_new_tokens=args.new_tokens, eos_token=50257, pad_token=50257,
                                    early_stopping=False, **kw)
 
-        def run_batch(lo, hi, engine=eng, mel_fn=fn, after_encode=None):
+        def run_batch(lo, hi):
             """One engine call on its own (the extra legs, no collective: the clamp maximum is that
             of the call's windows): log-mel, encoder, tokens."""
-            pieces, clip_max = log_mel_pieces([(lo, hi)], mel_fn, reduce=False)
-            engine.encode(finish_mel(pieces[0], clip_max, hi - lo, mel_fn))
-            if after_encode is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                after_encode(ev)
-            return decode(engine, hi - lo)
+            pieces, clip_max = log_mel_pieces([(lo, hi)], reduce=False)
+            eng.encode(finish_mel(pieces[0], clip_max, hi - lo))
+            return decode(eng, hi - lo)
 
         def step():
             pieces, clip_max = log_mel_pieces([(int(starts[i]), int(starts[i + 1])) for i in range(len(batches))])
@@ -592,16 +588,17 @@ def bench_whisper(args, rank, world):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = whisper_cpu_baseline(args, dims, weights, check)
-    # two engines have to fit the card: the pipelined leg runs calls of at most 256 windows
+    # the pipelined leg builds its own two engines (calls of at most 256 windows so that both fit the card)
+    del eng
+    torch.cuda.empty_cache()
     pb = min(per_call, 256)
     pbatches = [mine[i: i + pb] for i in range(0, len(mine), pb)]
     if args.pipelined and len(pbatches) >= 2:
         try:                                # every rank raises together (all_ranks_ok)
-            line["pipelined"] = bench_pipelined(args, dims, weights, eng, fn, run_batch, pbatches, world)
+            line["pipelined"] = bench_pipelined(args, dims, weights, fn, log_mel_pieces, finish_mel, decode, pbatches, world)
         except Exception as e:              # noqa: BLE001
             line["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    del eng
-    torch.cuda.empty_cache()
+        torch.cuda.empty_cache()
     if args.beam_windows > 0:
         try:
             line["beam5"] = bench_beam(args, dims, weights, fn, pcm, min(args.beam_windows, len(mine)))
@@ -735,22 +732,31 @@ def whisper_cpu_baseline(args, dims, weights, check):
                           "ok": bool(wrong == 0 and rel_l2 < 2e-2 and scores_ok)}}
 
 
-def bench_pipelined(args, dims, weights, eng0, fn0, run_batch, batches, world):
+def bench_pipelined(args, dims, weights, fn0, log_mel_pieces, finish_mel, decode, batches, world):
     """This rank's batches alternated over two engines built from the same weights, each on its own
     host thread and stream, the second one phase late: while one decodes a batch (HBM bound) the
     other runs the log-mel and the encoder of its next batch (matrix-core bound).  One pass over
     the rank's windows; the time includes the unoverlapped first and last phases."""
     import threading
-    from speech_to_text_amd.audio.stft import WhisperSTFT
     from speech_to_text_amd.engine import WhisperEngine
     dev = torch.device("cuda", torch.cuda.current_device())
     errors = []
-    engs, fns = [eng0], [fn0]
+    engs, fns = [], [fn0, fn0]               # log-mel plans are per stream
+
+    def run_batch(lo, hi, engine, mel_fn, after_encode=None):
+        pieces, clip_max = log_mel_pieces([(lo, hi)], mel_fn, reduce=False)
+        engine.encode(finish_mel(pieces[0], clip_max, hi - lo, mel_fn))
+        if after_encode is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            after_encode(ev)
+        return decode(engine, hi - lo)
+
     try:
-        engs.append(WhisperEngine(dims, weights, max_batch=len(batches[0]), max_beams=1,
-                                  max_text_len=args.new_tokens + len(PROMPT) + 1, max_prompt_len=4))
-        fns.append(fn0)                      # plans are per stream
-        run_batch(0, len(batches[0]), engs[1], fns[1])       # warm the second engine
+        for r in range(2):
+            engs.append(WhisperEngine(dims, weights, max_batch=len(batches[0]), max_beams=1,
+                                      max_text_len=args.new_tokens + len(PROMPT) + 1, max_prompt_len=4))
+            run_batch(0, len(batches[0]), engs[r], fns[r])       # warm the engine
         torch.cuda.synchronize()
     except Exception as e:                   # noqa: BLE001
         errors.append(e)

@@ -2,33 +2,35 @@
 # Re-creates this round's profile files under gpurun_out/r3 (summaries only; copied into profiles/r3 by hand).
 # Every GPU step has its own time limit and the script stops at the first failure.  Token steps are issued as
 # plain launches under the profiler (STT_MI355X_NO_GRAPH=1): it crashes on replayed graphs (profiles/README.md).
-# bash scripts/refresh_profiles_r3.sh [part ...]   parts: bench prof512 decode512 pmc512 beam encoder logmel
+# bash scripts/refresh_profiles_r3.sh [part ...]   parts: bench profdefault decode600 pmc600 decode512 pmc512 beam encoder logmel
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3
 mkdir -p $O
-parts=${@:-bench prof512 decode512 pmc512 beam encoder logmel}
+parts=${@:-bench profdefault decode600 pmc600 beam encoder logmel}
 cd /tmp
 last() { ls $1 | tail -n 1; }
 for part in $parts; do
 case $part in
 bench)
   timeout -k 10 560 python3 $R/bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err ;;
-prof512)
-  STT_MI355X_NO_GRAPH=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw -- python3 $R/bench.py --pipelined 0 --no-cpu-baseline --beam-windows 0 --logmel-steps 0 --steps 1 --warmup 0 > $O/bench512_profiled.json 2> $O/bench512_profiled.err
-  cp $(last "$O/raw/*/*kernel_stats.csv") $O/bench512_kernel_stats.csv
-  python3 $R/scripts/prof_shapes.py $(last "$O/raw/*/*kernel_trace.csv") 40 > $O/bench512_kernel_shapes.txt
+profdefault)
+  STT_MI355X_NO_GRAPH=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw -- python3 $R/bench.py --pipelined 0 --no-cpu-baseline --beam-windows 0 --logmel-steps 0 --steps 1 --warmup 0 > $O/bench_default_profiled.json 2> $O/bench_default_profiled.err
+  cp $(last "$O/raw/*/*kernel_stats.csv") $O/bench_default_kernel_stats.csv
+  python3 $R/scripts/prof_shapes.py $(last "$O/raw/*/*kernel_trace.csv") 40 > $O/bench_default_kernel_shapes.txt
   rm -rf $O/raw ;;
-decode512)
-  STT_MI355X_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python3 $R/scripts/prof_decode.py 512 32 > $O/decode512.log 2>&1
-  ( grep "per token" $O/decode512.log; python3 $R/scripts/prof_shapes.py $(last "$O/raw/*/*kernel_trace.csv") 40 ) > $O/decode512_kernel_shapes.txt
+decode512|decode600)
+  W=${part#decode}
+  STT_MI355X_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python3 $R/scripts/prof_decode.py $W 32 > $O/decode$W.log 2>&1
+  ( grep "per token" $O/decode$W.log; python3 $R/scripts/prof_shapes.py $(last "$O/raw/*/*kernel_trace.csv") 40 ) > $O/decode${W}_kernel_shapes.txt
   rm -rf $O/raw ;;
-pmc512)
+pmc512|pmc600)
+  W=${part#pmc}
   for c in FETCH_SIZE WRITE_SIZE; do
-    STT_MI355X_NO_GRAPH=1 timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $O/raw_$c -- python3 $R/scripts/prof_decode.py 512 8 > $O/pmc512_$c.log 2>&1
+    STT_MI355X_NO_GRAPH=1 timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $O/raw_$c -- python3 $R/scripts/prof_decode.py $W 8 > $O/pmc${W}_$c.log 2>&1
   done
-  python3 $R/scripts/pmc_hbm.py "scripts/prof_decode.py 512 8 (large-v3, 512 windows: one encoder pass, 3 x 8 greedy tokens as plain launches)" $(last "$O/raw_FETCH_SIZE/*/*counter_collection.csv") $(last "$O/raw_WRITE_SIZE/*/*counter_collection.csv") > $O/decode512_pmc_hbm.csv
+  python3 $R/scripts/pmc_hbm.py "scripts/prof_decode.py $W 8 (large-v3, $W windows: one encoder pass, 3 x 8 greedy tokens as plain launches)" $(last "$O/raw_FETCH_SIZE/*/*counter_collection.csv") $(last "$O/raw_WRITE_SIZE/*/*counter_collection.csv") > $O/decode${W}_pmc_hbm.csv
   rm -rf $O/raw_FETCH_SIZE $O/raw_WRITE_SIZE ;;
 beam)
   STT_MI355X_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/raw -- python3 $R/scripts/time_beam.py large-v3 100 32 > $O/beam100.log 2>&1

@@ -212,7 +212,7 @@ GemmArgs gemm_args(const bf16_t* a, long lda, const bf16_t* w, const float* bias
 // add_layernorm), *pending_slabs returns how many.
 // Up to this many rows a layer goes through the decode-step kernels (weights streamed once, split-K
 // partial sums consumed by the next kernel); above it through the tiled large-M kernels.
-constexpr int kDecodeRows = 512;
+constexpr int kDecodeRows = 640;       // (1 200 windows split evenly over two calls or two ranks: 600 rows per token step)
 // With a single row (one clip, greedy: the way the reference calls) the three LayerNorms of a
 // decoder layer and the final one run as the prologue of the projection that consumes them
 // (launch_gemm_skinny_ln): 8 instead of 11 launches per layer, same bits, 1.96 -> 1.80 ms per token

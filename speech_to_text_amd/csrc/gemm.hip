@@ -915,7 +915,7 @@ void launch_gemm_skinny_ln(const GemmArgs& g, const LnFuse& f, int epilogue, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Decode-step kernel for 32 < M <= 512 rows: a block owns 64 output features and up to 256 rows,
+// Decode-step kernel for 32 < M <= 640 rows: a block owns 64 output features and up to 256 rows,
 // so the activations are read once per 64 features instead of once per 16.  Both operands go
 // through a three-stage LDS ring filled by LDS-DMA in K chunks of 64 (same 128-byte rows and
 // source-side swizzle as the large kernel); stage t + 2 is requested while stage t is being
@@ -1087,7 +1087,7 @@ int pick_split_k(int m, int n, int k, int n_cu) {
   const int steps = k / 64;
   const int mt = (m + 15) / 16;
   int best = 1;
-  if (mt >= mid_from_tiles() && mt <= 32) {
+  if (mt >= mid_from_tiles() && mt <= 40) {
     // 64-feature blocks: split until about half the CUs have a block, at least 4 chunks each
     const int col_blocks = (n + 63) / 64;
     for (int s = 1; s <= 8 && s <= steps; ++s) {
@@ -1152,7 +1152,7 @@ static void launch_skinny_nt(const GemmArgs& g, int epilogue, int split_k, float
 void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,
                         hipStream_t stream) {
   const int mt = (g.m + 15) / 16;
-  if (mt >= mid_from_tiles() && mt <= 32 && (g.k / split_k) % 64 == 0) {
+  if (mt >= mid_from_tiles() && mt <= 40 && (g.k / split_k) % 64 == 0) {
     // All rows in one block (the weights are then read once) unless that leaves fewer blocks than
     // CUs: then the rows per block are halved until the chip is covered.  At 256 rows of
     // large-v3 this took the token step from 13.7 to 12.7 ms (QKV and FC1 had 60 and 80 blocks).

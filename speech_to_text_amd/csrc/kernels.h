@@ -46,7 +46,7 @@ struct GemmArgs {
 // Tiled MFMA GEMM for M >= a few hundred rows (encoder, prompt pass).
 void launch_gemm_big(const GemmArgs& g, int epilogue, hipStream_t stream);
 
-// Weight-streaming GEMM for M <= 256 rows (decode steps).  split_k > 1 writes raw fp32 partial
+// Weight-streaming GEMM for M <= 640 rows (decode steps).  split_k > 1 writes raw fp32 partial
 // sums to slabs[split_k][M][N] (no bias / activation); split_k == 1 applies the epilogue
 // (EPI_BF16, EPI_GELU_BF16 or EPI_F32).
 void launch_gemm_skinny(const GemmArgs& g, int epilogue, int split_k, float* slabs,

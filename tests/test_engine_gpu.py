@@ -104,16 +104,17 @@ def test_decoder_logits_row_counts(small, n_tokens):
     assert _rel_l2(got, ref) < 2e-2
 
 
-@pytest.mark.parametrize("n_tokens", [17, 24, 31, 32])
-def test_decoder_logits_up_to_512_rows(small, n_tokens):
-    """16 sequences x n_tokens rows = 272, 384, 496 and 512 rows: the 64-feature decode kernel with
-    two row groups per layer (what a 512-window token step runs), ragged and full."""
+@pytest.mark.parametrize("n_tokens", [17, 24, 31, 32, 33, 38, 40, 41])
+def test_decoder_logits_up_to_640_rows(small, n_tokens):
+    """16 sequences x n_tokens rows = 272, 384, 496, 512, 528, 608 and 640 rows: the 64-feature decode
+    kernel with several row groups per layer (what a 512- or 600-window token step runs), ragged and
+    full; and 656 rows, the first size that goes through the large tiled kernels instead."""
     from speech_to_text_amd.engine import WhisperEngine
     dims, _, oracle, mel = small
     if "wide" not in _LONG:
         w = _bf16_round(om.random_weights(dims, seed=0, style="peaked"))
         _LONG["wide"] = WhisperEngine(_dims_dict(dims), w, max_batch=16, max_beams=1, max_text_len=48,
-                                      max_prompt_len=32)
+                                      max_prompt_len=41)
     engine = _LONG["wide"]
     mel16 = torch.cat([mel, mel.flip(0), mel.flip(1), mel * 0.5, mel.flip(2), mel[:1]], dim=0)
     engine.encode(mel16)

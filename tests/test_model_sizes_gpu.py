@@ -141,22 +141,22 @@ def test_large_v3_all_layers():
 
 
 @pytest.mark.timeout(900)
-def test_large_v3_512_windows_per_call():
-    """The call the benchmark makes: all 32 + 32 layers of large-v3 over 512 windows at once (buffers
-    above 4 GiB, 768 000-row encoder GEMMs, 512-row decode GEMMs in two row groups).  The two fixture
-    windows sit at the first, middle and last positions of the batch (0 | 255 | 510 and 1 | 256 |
-    511) among 506 windows of noise: the copies must come out bit-identical wherever they sit, and at
+def test_large_v3_600_windows_per_call():
+    """The call the benchmark makes: all 32 + 32 layers of large-v3 over 600 windows at once (buffers
+    above 4 GiB, 900 000-row encoder GEMMs, 600-row decode GEMMs in five row groups).  The two fixture
+    windows sit at the first, middle and last positions of the batch (0 | 299 | 598 and 1 | 300 |
+    599) among 594 windows of noise: the copies must come out bit-identical wherever they sit, and at
     the last positions they must meet the fixture (encoder rows, greedy ids) and the oracle's
     step-by-step choice like the two-window call does."""
     from speech_to_text_amd.engine import WhisperEngine
     f, case, dims, w, mel2 = _fixture("large_v3_full")
     steps = case["steps"]
-    n = 512
+    n = 600
     engine = WhisperEngine(P.dims_dict(dims), w, max_batch=n, max_beams=1,
                            max_text_len=len(case["prompt"]) + steps + 1, max_prompt_len=4)
     g = torch.Generator(device="cuda").manual_seed(77)
     mel = torch.rand(n, 3000, dims.n_mels, generator=g, device="cuda") * 2 - 1
-    spots = {0: (0, 255, 510), 1: (1, 256, 511)}
+    spots = {0: (0, n // 2 - 1, n - 2), 1: (1, n // 2, n - 1)}
     for src, where in spots.items():
         for i in where:
             mel[i] = mel2[src].cuda()
@@ -171,7 +171,7 @@ def test_large_v3_512_windows_per_call():
             assert np.array_equal(tokens[i], tokens[where[0]]), (i, tokens[i], tokens[where[0]])
             assert scores[i] == scores[where[0]], (i, scores[i], scores[where[0]])
     assert len({tuple(r) for r in tokens.tolist()}) > 32              # the decode depends on the window's audio
-    last = [510, 511]
+    last = [n - 2, n - 1]
     enc_last = enc[last].cpu()
     del enc, mel
     _check_encoder_against_fixture(enc_last.numpy(), f)
@@ -183,7 +183,7 @@ def test_large_v3_512_windows_per_call():
         exact, total = P.check_greedy_steps(oracle, enc_last, prompt[:2], tokens[last], 50257, 50257,
                                             scores=scores[last])
     assert total == 2 * steps and exact >= total - int(_near_ties(f).sum()) - 1, (exact, total)
-    P.record_exact("large_v3_512_windows", exact, total)
+    P.record_exact("large_v3_600_windows", exact, total)
     del engine
     torch.cuda.empty_cache()
 
