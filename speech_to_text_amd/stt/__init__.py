@@ -1,1 +1,1 @@
-from .whisper import Whisper, WhisperVocabulary, transcribe, translate, search, get_model
+from .whisper import Whisper, WhisperVocabulary, transcribe, translate, stream, search, get_model

@@ -438,6 +438,32 @@ class Whisper(object):
             audios = [audios]
         return [self.infer(a, **kwargs) for a in audios]
 
+    def stream(self, stream, *, callback=None, **kwargs):
+        """`predict` over inputs that arrive one at a time, each result handed to `callback` instead of
+        being collected (models/stt/base_stt.py:391-396 over models/interfaces/base_model.py:714:
+        `predict(..., return_output = False, return_results = False)` fed by the reference's `Stream`,
+        which runs in the caller's thread here: `max_workers = 0`).  `stream` may be an iterable or
+        generator, a queue (anything with `.get()`; a `None` item ends it) or a callable returning the
+        next input (`None` ends it).  The frontend is run once on 0.5 s and 1 s of silence first, as the
+        reference does, so that the first real clip does not pay for plan creation.  Returns the number of
+        inputs processed."""
+        for length in (self.rate // 2, self.rate):
+            self.get_input({'audio': np.zeros((length,), dtype='float32'), 'rate': self.rate},
+                           normalize=False, trim_silence=False)
+        if hasattr(stream, 'get') and not isinstance(stream, dict):
+            items = iter(stream.get, None)
+        elif callable(stream):
+            items = iter(stream, None)
+        else:
+            items = iter(stream)
+        count = 0
+        for item in items:
+            result = self.infer(item, **kwargs)
+            count += 1
+            if callback is not None:
+                callback(result)
+        return count
+
     # ---- keyword search by partial alignment (README "Search and partial alignment")
     def search(self, keyword, audio, threshold=0.8, **kwargs):
         """Transcribes with timestamps and scores `keyword` against every segment's text with
@@ -479,6 +505,11 @@ def transcribe(audios, *, lang=None, model=None, **kwargs):
 def translate(audios, *, lang=None, model=None, **kwargs):
     """models/stt/__init__.py:48-51."""
     return get_model(lang=lang, model=model).predict(audios, lang=lang, task='translate', **kwargs)
+
+
+def stream(stream, *, lang=None, model=None, **kwargs):
+    """models/stt/__init__.py:53-55."""
+    return get_model(lang=lang, model=model).stream(stream, lang=lang, **kwargs)
 
 
 def search(keyword, audios, *, lang=None, model=None, **kwargs):

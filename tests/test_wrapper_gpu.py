@@ -304,3 +304,24 @@ def test_notebook_known_answer(golden_dir):
     assert len(res["segments"]) == 1 and abs(seg["end"] - 3.96) < 1e-9
     ids = [int(t) for t in seg["tokens"] if t < stt.eos_token_idx]
     assert ids == [440, 8481, 645, 9432, 293, 517, 35035, 457, 588, 6457, 2541, 13]
+
+
+def test_stream_hands_each_result_to_the_callback(model):
+    """`stream` (models/stt/__init__.py:53-55): inputs one at a time from a generator, a queue and a
+    callable; every result goes to the callback and equals what `predict` returns for that input."""
+    import queue
+    rng = np.random.default_rng(31)
+    clips = [rng.uniform(-1, 1, 16000 * s).astype(np.float32) for s in (3, 5)]
+    kw = dict(lang="en", max_length=12, normalize=False, trim_silence=False, logits_filter=NO_TIMESTAMPS,
+              early_stopping=False)
+    want = model.predict(list(clips), **kw)
+    q = queue.Queue()
+    for c in clips + [None]:
+        q.put(c)
+    feed = iter(clips + [None])
+    for source in ((c for c in clips), q, lambda: next(feed)):
+        got = []
+        assert model.stream(source, callback=got.append, **kw) == 2
+        assert [g["text"] for g in got] == [w["text"] for w in want]
+        for g, w in zip(got, want):
+            assert np.array_equal(g["segments"][0]["tokens"], w["segments"][0]["tokens"])
