@@ -450,10 +450,17 @@ class Whisper(object):
         for length in (self.rate // 2, self.rate):
             self.get_input({'audio': np.zeros((length,), dtype='float32'), 'rate': self.rate},
                            normalize=False, trim_silence=False)
+        def until_none(next_item):              # (`iter(f, None)` would compare arrays with None)
+            while True:
+                item = next_item()
+                if item is None:
+                    return
+                yield item
+
         if hasattr(stream, 'get') and not isinstance(stream, dict):
-            items = iter(stream.get, None)
+            items = until_none(stream.get)
         elif callable(stream):
-            items = iter(stream, None)
+            items = until_none(stream)
         else:
             items = iter(stream)
         count = 0
