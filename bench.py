@@ -683,9 +683,12 @@ def whisper_cpu_baseline(args, dims, weights, check):
     ids = torch.from_numpy(np.asarray(check["tokens"])).long()
     n_tok = ids.shape[1]
     with torch.no_grad():
-        t = time.perf_counter()
-        enc = oracle.encoder(mels)
-        t_enc = (time.perf_counter() - t) / n_w
+        encs, t_enc = [], 1e30
+        for i in range(n_w):                 # one window at a time; the first doubles as the warm-up: best of n_w
+            t = time.perf_counter()
+            encs.append(oracle.encoder(mels[i: i + 1]))
+            t_enc = min(t_enc, time.perf_counter() - t)
+        enc = torch.cat(encs)
         t = time.perf_counter()
         om.greedy(oracle, enc=enc[:1], prompt=torch.tensor([PROMPT]), max_new_tokens=n_tok, eos=50257,
                   pad=50257, early_stopping=False)
@@ -719,9 +722,9 @@ def whisper_cpu_baseline(args, dims, weights, check):
     scores_ok = bool((score_gap < slack + 0.02).all())
     return {"value": round(30.0 / per_window, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
             "seconds": round(t_enc * n_w + t_dec, 2), "host": host_cpu(),
-            "sample": "encoder over %d windows %.1f s each + cross K/V and %d greedy tokens of one window %.1f s "
+            "sample": "encoder of one window %.1f s (best of %d) + cross K/V and %d greedy tokens of one window %.1f s "
             "measured (torch-CPU fp32, oracle/model.py, the engine's bf16-rounded weights); value = 30 s / "
-            "(encoder + tokens scaled to %d)" % (n_w, t_enc, n_tok, t_dec, args.new_tokens),
+            "(encoder + tokens scaled to %d)" % (t_enc, n_w, n_tok, t_dec, args.new_tokens),
             "gpu_check": {"windows": "first and last window of a full engine call",
                           "prompt_logits_rel_l2": round(rel_l2, 5), "prompt_logits_tolerance": 2e-2,
                           "steps_checked": n_w * n_tok, "equal_oracle_argmax": exact,

@@ -1089,7 +1089,26 @@ int pick_split_k(int m, int n, int k, int n_cu) {
   int best = 1;
   if (mt >= mid_from_tiles() && mt <= 40) {
     // 64-feature blocks: split until about half the CUs have a block, at least 4 chunks each
+    static const int force_small = getenv("STT_MI355X_SPLIT_K1280") ? atoi(getenv("STT_MI355X_SPLIT_K1280")) : 0;
+    static const int force_large = getenv("STT_MI355X_SPLIT_K5120") ? atoi(getenv("STT_MI355X_SPLIT_K5120")) : 0;
+    if (mt > 16 && k <= 2048 && force_small > 0 && steps % force_small == 0) return force_small;
+    if (mt > 16 && k > 2048 && force_large > 0 && steps % force_large == 0) return force_large;
     const int col_blocks = (n + 63) / 64;
+    if (mt > 16) {
+      // Above 256 rows the rows are dealt to blocks of 128 (launch_gemm_skinny), two of which share
+      // a CU: the largest split that keeps every block in one round (<= 2 blocks per CU) and gives
+      // it at least 10 K chunks, so that its chunk loop outweighs its fill and its slab writes.
+      // Measured at 600 rows of large-v3: K = N = 1280 in 2 slices 9.2 us (5 slices 10.3, 1 slice
+      // 12.2) and a cheaper LayerNorm behind it; FC2 (K = 5120) in 5 slices 15.8 us (8 slices: two
+      // rounds, 23.1; 4 slices 19.1; 2 slices 21.4).
+      const int row_groups = (mt + 7) / 8;
+      for (int s = 1; s <= 8 && s <= steps; ++s) {
+        if (steps % s) continue;
+        if (steps / s < 10 || (long)col_blocks * s * row_groups > 2L * n_cu) break;
+        best = s;
+      }
+      return best;
+    }
     for (int s = 1; s <= 8 && s <= steps; ++s) {
       if (steps % s) continue;
       if (steps / s < 4) break;
