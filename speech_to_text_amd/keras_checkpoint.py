@@ -31,9 +31,12 @@ from .hdf5_lite import Hdf5File
 
 
 def latest_checkpoint(directory):
-    """The newest `*.weights.h5` of a model directory (or of its `saving/` folder), or None.
-    `checkpoint.json` names the checkpoints the manager keeps (checkpoint_manager.py:169-216); without
-    it the highest counter wins."""
+    """The `*.weights.h5` a model directory (or its `saving/` folder) is restored from, or None.
+    With a `checkpoint.json` it is the one the reference's CheckpointManager would load
+    (custom_train_objects/checkpoint_manager.py:88-98, 169-190): `loaded` indexes the list
+    `checkpoints`, whose entry's `counter` names the file `ckpt-{counter:04d}.weights.h5`; `loaded =
+    'best'` means `best.weights.h5` when it exists, else the newest entry.  Without that file (or when
+    it names a file that is gone) the highest counter wins."""
     for folder in (os.path.join(directory, "saving"), directory):
         found = sorted(glob.glob(os.path.join(folder, "*.weights.h5")))
         if not found:
@@ -43,14 +46,16 @@ def latest_checkpoint(directory):
             try:
                 with open(state) as f:
                     info = json.load(f)
-                for key in ("latest", "latest_checkpoint", "last"):
-                    name = info.get(key) if isinstance(info, dict) else None
-                    if isinstance(name, str):
-                        cand = os.path.join(folder, os.path.basename(name))
-                        cand = cand if cand.endswith(".weights.h5") else cand + ".weights.h5"
-                        if os.path.exists(cand):
-                            return cand
-            except (OSError, ValueError):
+                entries, loaded = info.get("checkpoints") or [], info.get("loaded", -1)
+                best = os.path.join(folder, "best.weights.h5")
+                if loaded == "best" and os.path.exists(best):
+                    return best
+                if entries:
+                    entry = entries[loaded] if isinstance(loaded, int) and -len(entries) <= loaded < len(entries) else entries[-1]
+                    cand = os.path.join(folder, "ckpt-%04d.weights.h5" % int(entry["counter"]))
+                    if os.path.exists(cand):
+                        return cand
+            except (OSError, ValueError, KeyError, TypeError):
                 pass
         numbered = [p for p in found if re.search(r"ckpt-\d+\.weights\.h5$", p)]
         return (numbered or found)[-1]

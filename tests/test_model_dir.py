@@ -77,6 +77,19 @@ def test_model_configuration_is_read_and_checked(model_dir, tmp_path):
         MI355XRuntime.load_engine(str(copy))
     shutil.copy(copy / "saving" / "ckpt-0001.weights.h5", copy / "saving" / "ckpt-0003.weights.h5")
     assert kc.latest_checkpoint(str(copy)).endswith("ckpt-0003.weights.h5")
+    # with the manager's own state file: the checkpoint it would restore (checkpoint_manager.py:88-98)
+    state = {"counter": 4, "loaded": 0, "best_checkpoint": {},
+             "checkpoints": [{"epoch": 1, "step": 10, "counter": 1}, {"epoch": 3, "step": 30, "counter": 3}]}
+    json.dump(state, open(copy / "saving" / "checkpoint.json", "w"))
+    assert kc.latest_checkpoint(str(copy)).endswith("ckpt-0001.weights.h5")
+    state["loaded"] = 1
+    json.dump(state, open(copy / "saving" / "checkpoint.json", "w"))
+    assert kc.latest_checkpoint(str(copy)).endswith("ckpt-0003.weights.h5")
+    state["loaded"] = "best"
+    json.dump(state, open(copy / "saving" / "checkpoint.json", "w"))
+    assert kc.latest_checkpoint(str(copy)).endswith("ckpt-0003.weights.h5")        # no best.weights.h5: the newest
+    shutil.copy(copy / "saving" / "ckpt-0001.weights.h5", copy / "saving" / "best.weights.h5")
+    assert kc.latest_checkpoint(str(copy)).endswith("best.weights.h5")
     assert kc.load_model_dir(str(tmp_path)) is None
 
 
