@@ -1091,8 +1091,8 @@ int pick_split_k(int m, int n, int k, int n_cu) {
     // 64-feature blocks: split until about half the CUs have a block, at least 4 chunks each
     static const int force_small = getenv("STT_MI355X_SPLIT_K1280") ? atoi(getenv("STT_MI355X_SPLIT_K1280")) : 0;
     static const int force_large = getenv("STT_MI355X_SPLIT_K5120") ? atoi(getenv("STT_MI355X_SPLIT_K5120")) : 0;
-    if (mt > 16 && k <= 2048 && force_small > 0 && steps % force_small == 0) return force_small;
-    if (mt > 16 && k > 2048 && force_large > 0 && steps % force_large == 0) return force_large;
+    if (k <= 2048 && force_small > 0 && steps % force_small == 0) return force_small;     // (measurement hooks)
+    if (k > 2048 && force_large > 0 && steps % force_large == 0) return force_large;
     const int col_blocks = (n + 63) / 64;
     if (mt > 16) {
       // Above 256 rows the rows are dealt to blocks of 128 (launch_gemm_skinny), two of which share
