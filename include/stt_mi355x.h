@@ -200,6 +200,37 @@ int stt_decoder_forward(stt_engine* engine, const int32_t* tokens, int batch, in
 int stt_decode_step(stt_engine* engine, const int32_t* d_tokens, int n_seq, int seq_per_window,
                     int n_tokens, int reset, const int32_t* d_parents, float* d_logits, void* stream);
 
+/* stt_decode_step that also returns the attention weights of decoder layers first_layer ..
+ * n_text_layer - 1, what the reference collects when its loop runs with `return_attention`
+ * (first_layer = 0) or `return_last_attention` (first_layer = n_text_layer - 1):
+ * architectures/transformers/transformer_arch.py:697-703 ('attn_<layer>' / 'enc_attn_<layer>'),
+ * accumulated over the steps by generation_utils.py:576-610.  Either pointer may be NULL.
+ *  d_self_attention: device float32 [layers][n_seq][heads][n_tokens][history + n_tokens], where
+ *   history = positions in the cache before this call (0 with reset); entries past a token's own
+ *   position are 0 (the causal mask, transformer_arch.py:186-195).
+ *  d_cross_attention: device float32 [layers][n_seq][heads][n_tokens][1500].
+ * The logits are those of stt_decode_step bit for bit when a window has one or two new rows
+ * (token steps of a greedy loop); with 3..16 rows per window (a prompt pass, beams) this call runs
+ * the vector-unit cross-attention kernel where the plain one runs the matrix-core kernel: the same
+ * sums in another order. */
+int stt_decode_step_attention(stt_engine* engine, const int32_t* d_tokens, int n_seq, int seq_per_window,
+                              int n_tokens, int reset, const int32_t* d_parents, float* d_logits,
+                              int first_layer, float* d_self_attention, float* d_cross_attention,
+                              void* stream);
+
+/* The decoder state of one layer as the reference's loop returns it with `return_state`
+ * (generation_utils.py:298, 478; per layer ((k, v) of the self-attention, (k, v) of the encoder
+ * attention): transformer_arch.py:440-475, residual_multi_head_attention.py:237-245, 313), copied
+ * out of the engine as float32 [n][heads][length][64].
+ *  cross = 0: the self-attention cache of the stt_decode_step history (n = its sequences, length
+ *   = its positions: stt_engine_step_state), each sequence's positions gathered from wherever
+ *   beam re-linking left them.  cross = 1: the encoder-attention K/V of the last stt_encode
+ *   (n = its windows, length = 1500). */
+int stt_engine_export_state(stt_engine* engine, int layer, int cross, float* d_k, float* d_v, void* stream);
+/* Sequences, sequences per window and cached positions of the current stt_decode_step history
+ * (all 0 / 1 / 0 when there is none).  Any pointer may be NULL. */
+int stt_engine_step_state(const stt_engine* engine, int* n_seq, int* seq_per_window, int* length);
+
 /* Measurement aid, no counterpart in the reference: enqueues on `stream` one launch of a hot
  * kernel exactly as a greedy token step over the last encoded batch issues it, so that a
  * benchmark can bracket it with events on its own stream (inside stt_generate the kernel runs

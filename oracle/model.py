@@ -250,8 +250,10 @@ class Whisper:
                        _split(r(linear(enc, self.w, p + "value")), self.dims.n_text_head)))
         return kv
 
-    def decoder(self, tokens, cross, cache=None, offset=0):
-        """tokens [B, S] at positions offset.. -> logits [B, S, V], new self cache.
+    def decoder(self, tokens, cross, cache=None, offset=0, return_attention=False):
+        """tokens [B, S] at positions offset.. -> logits [B, S, V], new self cache (and, with
+        `return_attention`, the dict {'attn_layer_<i>': [B, H, S, offset + S], 'enc_attn_layer_<i>':
+        [B, H, S, 1500]} of transformer_arch.py:697-703).
         token + learned position embedding, no scaling (text_transformer_arch.py:173-193,
         399-443); per layer self-attn -> cross-attn -> LN -> FFN; final LN; logits with the
         tied embedding (gpt2_arch.py:98-101)."""
@@ -262,21 +264,35 @@ class Whisper:
         if s > 1:
             total = offset + s
             mask = (torch.arange(total)[None, :] <= (offset + torch.arange(s))[:, None])[None, None]
-        new_cache = []
+        new_cache, weights = [], {}
+
+        def probabilities(q, k, m=None):
+            logits = torch.einsum("bhij,bhkj->bhik", q, k) / math.sqrt(q.shape[-1])
+            if m is not None:
+                logits = torch.where(m, logits, torch.tensor(float("-inf")))
+            return torch.softmax(logits, dim=-1)
+
         for i in range(dims.n_text_layer):
             p = "decoder.blocks.%d." % i
+            hq = self.r(layer_norm(x, w, p + "attn_ln")) if return_attention else None
             x, kv = self._self_block(x, p, dims.n_text_head, mask, None if cache is None else cache[i])
             new_cache.append(kv)
+            if return_attention:
+                qs = _split(self.r(linear(hq, w, p + "attn.query")), dims.n_text_head)
+                weights["attn_layer_%d" % i] = probabilities(qs, kv[0], mask)
             h = self.r(layer_norm(x, w, p + "cross_attn_ln"))
             q = linear(h, w, p + "cross_attn.query")
             if b * s > 256:                 # the engine's large-row path stores the query in bf16
                 q = self.r(q)
             q = _split(q, dims.n_text_head)
+            if return_attention:
+                weights["enc_attn_layer_%d" % i] = probabilities(q, cross[i][0])
             o = linear(self.r(_merge(attention(q, cross[i][0], cross[i][1]))), w, p + "cross_attn.out")
             x = x + o
             x = self._mlp_block(x, p)
         x = self.r(layer_norm(x, w, "decoder.ln"))
-        return x @ w["decoder.token_embedding.weight"].T, new_cache
+        logits = x @ w["decoder.token_embedding.weight"].T
+        return (logits, new_cache, weights) if return_attention else (logits, new_cache)
 
 
 # ---------------------------------------------------------------------------

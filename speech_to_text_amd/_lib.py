@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("STT_MI355X_LIB", os.path.join(_HERE, "libstt_mi355x.s
 
 _c = ctypes
 _lib = None
-ABI_VERSION = 4          # include/stt_mi355x.h: bumped on any signature or structure change
+ABI_VERSION = 5          # include/stt_mi355x.h: bumped on any signature or structure change
 
 
 class SttError(RuntimeError):

@@ -346,6 +346,10 @@ __global__ __launch_bounds__(64) void attn_decoder_self_kernel(const SelfAttnArg
       o.z = pack2(acc[4], acc[5]); o.w = pack2(acc[6], acc[7]);
       *(uint4*)(a.out + (long)(i * a.s_new + j) * d_model + h * 64 + 8 * piece) = o;
     }
+    if (a.probs) {
+      float* dst = a.probs + (((long)i * a.heads + h) * a.s_new + j) * a.probs_len;
+      for (int key = lane; key < a.probs_len; key += 64) dst[key] = key < n_keys ? __expf(probs[key] - mx) * inv : 0.f;
+    }
     __syncthreads();
   }
 }
@@ -545,6 +549,19 @@ __global__ __launch_bounds__(64 * NWV) void attn_decoder_cross_kernel(const Cros
       const float inv = 1.0f / den;
       const float v = num * inv;
       a.out[(row0 + qc + qi) * d_model + h * 64 + d] = f2bf(v);
+    }
+    if (a.probs) {
+#pragma unroll
+      for (int qi = 0; qi < CQ; ++qi) {
+        if (qi >= nq) break;
+        float den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) den += wsum[w][qi];
+        const float inv = 1.0f / den;
+        const long row = row0 + qc + qi, seq = row / a.s_new, j = row - seq * a.s_new;
+        float* dst = a.probs + ((seq * a.heads + h) * a.s_new + j) * T;
+        for (int key = tid; key < T; key += 64 * NWV) dst[key] = __expf(sc[qi][key] - mx[qi]) * inv;
+      }
     }
     __syncthreads();
   }
@@ -770,7 +787,7 @@ void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream) {
   const int nq = a.seq_per_win * a.s_new;
   const dim3 grid(a.heads, a.n_win);
   static const bool no_mfma = getenv("STT_MI355X_CROSS_VALU") != nullptr;      // A/B and test hook
-  if (nq >= 3 && nq <= 16 && !no_mfma) {
+  if (nq >= 3 && nq <= 16 && !no_mfma && !a.probs) {      // (the weights are written by the vector-unit kernel)
     hipLaunchKernelGGL(attn_decoder_cross_mfma_kernel, grid, dim3(256), 0, stream, a);
     return;
   }

@@ -62,6 +62,11 @@ struct stt_engine {
   std::vector<bf16_t*> cross_k, cross_v;
   int enc_batch = 0;       // windows held by the last stt_encode
   int step_len = 0, step_seqs = 0;   // stt_decode_step: positions in the cache, sequences of the history
+  int step_per_window = 1;
+  // stt_decode_step_attention: where the pass in progress leaves its attention weights (null otherwise)
+  float* attn_self_out = nullptr;
+  float* attn_cross_out = nullptr;
+  int attn_first_layer = 0, attn_len = 0;
 
   // decoder buffers
   int max_seq = 0, max_rows = 0;
@@ -602,14 +607,20 @@ int decoder_pass(stt_engine* e, int n_seq, int seq_per_win, int s_new, bool last
       dense(e, e->dh, d, L.wqkv, L.bqkv, rows, 3 * d, d, EPI_BF16, e->dqkv, 3 * d, nullptr, st);
     }
     SelfAttnArgs sa{e->dqkv, e->self_k[l], e->self_v[l], e->gs.slot_of, e->gs.base_len, e->datt,
-                    n_seq, s_new, H, e->max_len, finished};
+                    n_seq, s_new, H, e->max_len, finished, nullptr, 0};
+    if (e->attn_self_out && l >= e->attn_first_layer) {
+      sa.probs = e->attn_self_out + (long)(l - e->attn_first_layer) * rows * H * e->attn_len;
+      sa.probs_len = e->attn_len;
+    }
     launch_attn_decoder_self(sa, st);
     dense(e, e->datt, d, L.wo, L.bo, rows, d, d, EPI_RESID_F32, e->dx, d, &pend, st);
     pend_bias = L.bo;
     // decode steps: the query projection is split over K like the residual projections (twice
     // the blocks of an unsplit launch) and the attention kernel sums the slabs as it loads q
     CrossAttnArgs ca{e->dq, nullptr, 0, 0, nullptr, e->cross_k[l], e->cross_v[l], e->datt,
-                     n_seq / seq_per_win, seq_per_win, s_new, H, 1500, finished};
+                     n_seq / seq_per_win, seq_per_win, s_new, H, 1500, finished, nullptr};
+    if (e->attn_cross_out && l >= e->attn_first_layer)
+      ca.probs = e->attn_cross_out + (long)(l - e->attn_first_layer) * rows * H * 1500;
     if (fuse) {
       const int sq = pick_split_k(rows, d, d, e->n_cu);
       ln_dense(L.lncg, L.lncb, L.wq_c, nullptr, d, -1, nullptr, d, sq, e->slabs2);
@@ -694,6 +705,18 @@ __global__ void relink_commit_kernel(GenState s, int max_len) {
     s.slot_of[(long)i * max_len + q] = s.slot_of_tmp[(long)i * max_len + q];
   if (threadIdx.x == 0) s.base_len[i] = s.lengths_tmp[i];
 }
+// [n][heads][length][64] fp32 out of a cache [slot][heads][pitch][64] bf16; slot_of (or null: slot = n)
+__global__ void export_cache_kernel(const bf16_t* cache, const int* slot_of, int slot_of_pitch, float* out,
+                                    int heads, int pitch, int length) {
+  const int i = blockIdx.y, h = blockIdx.x;
+  for (long e = threadIdx.x; e < (long)length * 64; e += blockDim.x) {
+    const int p = (int)(e >> 6);
+    const int slot = slot_of ? slot_of[(long)i * slot_of_pitch + p] : i;
+    out[(((long)i * heads + h) * length) * 64 + e] =
+        __uint_as_float((uint32_t)cache[(((long)slot * heads + h) * pitch) * 64 + e] << 16);
+  }
+}
+
 __global__ void fill_int_kernel(int* p, long n, int v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -720,6 +743,55 @@ int stt_decoder_forward(stt_engine* e, const int32_t* tokens, int batch, int n_t
   int rc = decoder_pass(e, batch, 1, n_tokens, false, d_logits, st);
   if (rc) return rc;
   STT_HIP_OR_FAIL(hipStreamSynchronize(st), (void)0);     // `pos` is a host temporary
+  return STT_OK;
+}
+
+int stt_decode_step_attention(stt_engine* e, const int32_t* d_tokens, int n_seq, int seq_per_window, int n_tokens,
+                              int reset, const int32_t* d_parents, float* d_logits, int first_layer,
+                              float* d_self_attention, float* d_cross_attention, void* stream_) {
+  if (!e) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (first_layer < 0 || first_layer >= e->cfg.n_text_layer)
+    return stt_fail(STT_ERR_INVALID_ARGUMENT, "first_layer %d of %d decoder layers", first_layer, e->cfg.n_text_layer);
+  e->attn_self_out = d_self_attention;
+  e->attn_cross_out = d_cross_attention;
+  e->attn_first_layer = first_layer;
+  e->attn_len = (reset ? 0 : e->step_len) + n_tokens;
+  const int rc = stt_decode_step(e, d_tokens, n_seq, seq_per_window, n_tokens, reset, d_parents, d_logits, stream_);
+  e->attn_self_out = e->attn_cross_out = nullptr;
+  return rc;
+}
+
+int stt_engine_export_state(stt_engine* e, int layer, int cross, float* d_k, float* d_v, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  if (!e || !d_k || !d_v) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!e->finalized || !e->buffers_ok) return stt_fail(STT_ERR_INVALID_ARGUMENT, "engine not finalized");
+  if (layer < 0 || layer >= e->cfg.n_text_layer) return stt_fail(STT_ERR_INVALID_ARGUMENT, "no such layer");
+  const int H = e->cfg.n_text_head;
+  if (cross) {
+    if (e->enc_batch < 1) return stt_fail(STT_ERR_INVALID_ARGUMENT, "nothing encoded");
+    const dim3 grid(H, e->enc_batch);
+    hipLaunchKernelGGL(export_cache_kernel, grid, dim3(256), 0, st, e->cross_k[layer], (const int*)nullptr, 0, d_k,
+                       H, 1500, 1500);
+    hipLaunchKernelGGL(export_cache_kernel, grid, dim3(256), 0, st, e->cross_v[layer], (const int*)nullptr, 0, d_v,
+                       H, 1500, 1500);
+  } else {
+    if (e->step_len < 1 || e->step_seqs < 1)
+      return stt_fail(STT_ERR_INVALID_ARGUMENT, "no stt_decode_step history to export");
+    const dim3 grid(H, e->step_seqs);
+    hipLaunchKernelGGL(export_cache_kernel, grid, dim3(256), 0, st, e->self_k[layer], e->gs.slot_of, e->max_len, d_k,
+                       H, e->max_len, e->step_len);
+    hipLaunchKernelGGL(export_cache_kernel, grid, dim3(256), 0, st, e->self_v[layer], e->gs.slot_of, e->max_len, d_v,
+                       H, e->max_len, e->step_len);
+  }
+  STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
+  return STT_OK;
+}
+
+int stt_engine_step_state(const stt_engine* e, int* n_seq, int* seq_per_window, int* length) {
+  if (!e) return stt_fail(STT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_seq) *n_seq = e->step_seqs;
+  if (seq_per_window) *seq_per_window = e->step_per_window;
+  if (length) *length = e->step_len;
   return STT_OK;
 }
 
@@ -756,6 +828,7 @@ int stt_decode_step(stt_engine* e, const int32_t* d_tokens, int n_seq, int seq_p
                      n_tokens);
   e->step_len += n_tokens;
   e->step_seqs = n_seq;
+  e->step_per_window = seq_per_window;
   STT_HIP_OR_FAIL(hipGetLastError(), (void)0);
   return STT_OK;
 }

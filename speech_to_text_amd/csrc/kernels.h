@@ -112,6 +112,9 @@ struct SelfAttnArgs {
   const int* finished; // null, or [n_seq]: a sequence whose flag is set is skipped (nothing appended, its
                        // output rows left as they are): its next token is the pad token whatever the
                        // decoder computes (generation_utils.py:234-236)
+  float* probs;        // null, or [n_seq][heads][s_new][probs_len] fp32: the attention weights of this pass
+  int probs_len;       // (zero past a token's own position), what the reference returns as 'attn_<layer>'
+                       // (architectures/transformers/transformer_arch.py:697-703)
 };
 // Appends the new k,v at positions base_len[i] .. +s_new-1 of sequence i (writing into slot i)
 // and attends causally over positions 0 .. base_len[i] + j for new token j.
@@ -129,6 +132,7 @@ struct CrossAttnArgs {
   int n_win, seq_per_win, s_new, heads, t_enc;
   const int* finished; // null, or [n_win * seq_per_win]: a window all of whose sequences are finished is
                        // skipped (its K/V are not read, its output rows left as they are)
+  float* probs;        // null, or [n_seq][heads][s_new][t_enc] fp32: the attention weights ('enc_attn_<layer>')
 };
 void launch_attn_decoder_cross(const CrossAttnArgs& a, hipStream_t stream);
 

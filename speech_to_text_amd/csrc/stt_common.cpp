@@ -11,4 +11,4 @@ int stt_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* stt_last_error(void) { return g_last_error; }
-extern "C" int stt_abi_version(void) { return 4; }
+extern "C" int stt_abi_version(void) { return 5; }

@@ -142,6 +142,7 @@ class WhisperEngine(object):
                     self._h, name.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), arr.size))
             _lib.check(self._lib.stt_engine_finalize(self._h))
         self._batch = 0
+        self._epoch = 0          # bumped by every call that changes the decoder state (see eager.EngineState)
 
     def __del__(self):
         try:
@@ -156,6 +157,7 @@ class WhisperEngine(object):
         new buffers do not fit the card the call raises and the engine is back at its previous
         capacity (or, if even that no longer fits, unusable until a reserve succeeds: `usable()`)."""
         self._batch = 0
+        self._epoch += 1
         with torch.cuda.device(self.device):
             _lib.check(self._lib.stt_engine_reserve(self._h, int(max_batch), int(max_beams),
                                                     int(max_text_len), int(max_prompt_len)))
@@ -191,6 +193,7 @@ class WhisperEngine(object):
             mel = mel[:, :3000].contiguous()
             frames = 3000
         out = None
+        self._epoch += 1
         with torch.cuda.device(self.device):
             if return_output:
                 out = torch.empty((b, 1500, self.dims["n_audio_state"]), dtype=torch.float32, device=self.device)
@@ -211,12 +214,16 @@ class WhisperEngine(object):
                 self._h, tokens.ctypes.data_as(C.POINTER(C.c_int32)), b, s, out.data_ptr(), self._stream()))
         return out
 
-    def decode_step(self, tokens, seq_per_window=1, reset=False, parents=None):
+    def decode_step(self, tokens, seq_per_window=1, reset=False, parents=None, attention=None):
         """One cached decoder step (stt_decode_step): `tokens` int32 [n_seq, n_tokens] (CUDA tensor or
         array) are appended to the sequences' histories and the logits of the last position come
         back as a float32 CUDA tensor [n_seq, V].  `reset` starts the histories afresh (the prompt);
         `parents` int32 [n_seq] re-links sequence i to the history of sequence parents[i] first
-        (beam search).  Selection is the caller's: see speech_to_text_amd/eager.py."""
+        (beam search).  Selection is the caller's: see speech_to_text_amd/eager.py.
+        `attention`: None, 'last', 'all' or a first decoder layer: the call then returns
+        (logits, self_attention [layers, n_seq, heads, n_tokens, positions so far],
+        cross_attention [layers, n_seq, heads, n_tokens, 1500]) for those layers
+        (stt_decode_step_attention)."""
         if not isinstance(tokens, torch.Tensor):
             tokens = torch.from_numpy(np.ascontiguousarray(np.asarray(tokens, dtype=np.int32)))
         tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous()
@@ -229,17 +236,55 @@ class WhisperEngine(object):
             parents = parents.to(device=self.device, dtype=torch.int32).contiguous()
             if parents.numel() != n_seq:
                 raise ValueError("parents must name one sequence per sequence")
+        self._epoch += 1
         with torch.cuda.device(self.device):
             out = torch.empty((n_seq, self.dims["n_vocab"]), dtype=torch.float32, device=self.device)
-            _lib.check(self._lib.stt_decode_step(
+            if attention is None:
+                _lib.check(self._lib.stt_decode_step(
+                    self._h, tokens.data_ptr(), n_seq, int(seq_per_window), n_tok, 1 if reset else 0,
+                    parents.data_ptr() if parents is not None else None, out.data_ptr(), self._stream()))
+                return out
+            n_layer, heads = self.dims["n_text_layer"], self.dims["n_text_head"]
+            first = {"all": 0, "last": n_layer - 1}.get(attention, attention)
+            if not isinstance(first, int) or not 0 <= first < n_layer:
+                raise ValueError("attention must be None, 'last', 'all' or a decoder layer, got {!r}".format(attention))
+            total = (0 if reset else self.step_state()[2]) + n_tok
+            own = torch.empty((n_layer - first, n_seq, heads, n_tok, total), dtype=torch.float32, device=self.device)
+            enc = torch.empty((n_layer - first, n_seq, heads, n_tok, 1500), dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.stt_decode_step_attention(
                 self._h, tokens.data_ptr(), n_seq, int(seq_per_window), n_tok, 1 if reset else 0,
-                parents.data_ptr() if parents is not None else None, out.data_ptr(), self._stream()))
-        return out
+                parents.data_ptr() if parents is not None else None, out.data_ptr(), first,
+                own.data_ptr(), enc.data_ptr(), self._stream()))
+        return out, own, enc
+
+    def step_state(self):
+        """(sequences, sequences per window, cached positions) of the current decode_step history."""
+        n, per, length = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self._lib.stt_engine_step_state(self._h, C.byref(n), C.byref(per), C.byref(length)))
+        return n.value, per.value, length.value
+
+    def export_state(self, layer):
+        """((k, v), (enc_k, enc_v)) of decoder layer `layer`, float32 CUDA tensors [n, heads, length,
+        64]: the self-attention cache of the decode_step history and the encoder-attention K/V of
+        the encoded batch - the layer's entry of the state the reference's loop returns
+        (architectures/transformers/transformer_arch.py:440-475)."""
+        n, _, length = self.step_state()
+        heads = self.dims["n_text_head"]
+        with torch.cuda.device(self.device):
+            k = torch.empty((n, heads, length, 64), dtype=torch.float32, device=self.device)
+            v = torch.empty_like(k)
+            ek = torch.empty((self._batch, heads, 1500, 64), dtype=torch.float32, device=self.device)
+            ev = torch.empty_like(ek)
+            _lib.check(self._lib.stt_engine_export_state(self._h, int(layer), 0, k.data_ptr(), v.data_ptr(), self._stream()))
+            _lib.check(self._lib.stt_engine_export_state(self._h, int(layer), 1, ek.data_ptr(), ev.data_ptr(), self._stream()))
+        return (k, v), (ek, ev)
 
     def generate(self, prompt, *, method="greedy", num_beams=1, num_sentences=1, max_new_tokens,
                  eos_token, pad_token, early_stopping=True, temperature=None, length_temperature=None,
                  length_power=None, logits_filter=None, check_every=8, sample=None, seed=None,
-                 return_logits=False, filter_kwargs=None, max_new_tokens_per_window=None):
+                 return_logits=False, filter_kwargs=None, max_new_tokens_per_window=None,
+                 return_attention=False, return_last_attention=False, return_state=False,
+                 initial_state=None, extras=None):
         """`temperature` given (and not 0) means, as in the reference (generation_utils.py:538-548),
         that tokens are drawn from the categorical distribution of the processed scores instead of
         taking the argmax / top-k; `sample = False` keeps the rescaling but not the draw.  `seed`
@@ -253,7 +298,25 @@ class WhisperEngine(object):
         `return_logits` under beam search - runs the loop in Python over `decode_step` (eager.py).
         `max_new_tokens_per_window` [batch]: a window ends after that many new tokens, exactly as a call
         of its own with that `max_new_tokens` would (device loop only); with early stopping on, windows
-        that have ended - by EOS or by their limit - cost no attention traffic any more."""
+        that have ended - by EOS or by their limit - cost no attention traffic any more.
+        `return_attention` / `return_last_attention` / `return_state` / `initial_state`: the reference's
+        options of the same names (generation_utils.py:84-87, 293-300); they run the loop in Python
+        too and leave their results in the dict passed as `extras` ('attention_weights', 'state')."""
+        if return_attention or return_last_attention or return_state or initial_state is not None:
+            from . import eager
+            if callable(logits_filter) and not isinstance(logits_filter, TimestampFilter):
+                logits_filter = TimestampFilter.from_callable(logits_filter) or logits_filter
+            if isinstance(logits_filter, TimestampFilter):
+                logits_filter = logits_filter.as_callable()
+            return eager.generate(
+                self, prompt, method=method, num_beams=num_beams, num_sentences=num_sentences,
+                max_new_tokens=max_new_tokens, eos_token=eos_token, pad_token=pad_token,
+                early_stopping=early_stopping, temperature=temperature,
+                length_temperature=length_temperature, length_power=length_power,
+                logits_filter=logits_filter, return_logits=return_logits, seed=seed, check_every=check_every,
+                filter_kwargs=filter_kwargs, return_attention=return_attention,
+                return_last_attention=return_last_attention, return_state=return_state,
+                initial_state=initial_state, extras=extras)
         prompt = np.ascontiguousarray(np.asarray(prompt, dtype=np.int32))
         if prompt.ndim == 1:
             prompt = prompt[None]
@@ -329,6 +392,7 @@ class WhisperEngine(object):
         lengths = np.empty((b, nsent), dtype=np.int32)
         scores = np.empty((b, nsent), dtype=np.float32)
         logits = None
+        self._epoch += 1
         with torch.cuda.device(self.device):
             if return_logits:
                 logits = torch.full((b, p.max_steps, self.dims["n_vocab"]), float("-inf"),
@@ -367,6 +431,12 @@ def _declare(lib):
     lib.stt_engine_usable.argtypes = [vp]
     lib.stt_decode_step.restype = i32
     lib.stt_decode_step.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.stt_decode_step_attention.restype = i32
+    lib.stt_decode_step_attention.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp]
+    lib.stt_engine_export_state.restype = i32
+    lib.stt_engine_export_state.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.stt_engine_step_state.restype = i32
+    lib.stt_engine_step_state.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.stt_engine_probe_kernel.restype = i32
     lib.stt_engine_probe_kernel.argtypes = [vp, i32, i32, vp]
     lib.stt_encode.restype = i32
@@ -380,4 +450,5 @@ def _declare(lib):
 
 
 ENGINE_SYMBOLS = ("stt_engine_create", "stt_engine_destroy", "stt_engine_set_weight",
-                  "stt_engine_finalize", "stt_engine_reserve", "stt_engine_usable", "stt_engine_probe_kernel", "stt_decode_step", "stt_encode", "stt_decoder_forward", "stt_generate")
+                  "stt_engine_finalize", "stt_engine_reserve", "stt_engine_usable", "stt_engine_probe_kernel", "stt_decode_step",
+                  "stt_decode_step_attention", "stt_engine_export_state", "stt_engine_step_state", "stt_encode", "stt_decoder_forward", "stt_generate")

@@ -182,7 +182,8 @@ class MI355XRuntime(Runtime):
                  max_length=None, max_new_tokens=None, method='greedy', num_beams=10,
                  num_sentences=1, temperature=None, length_temperature=None, length_power=None,
                  logits_filter=None, early_stopping=True, seed=None, replica=0, on_encoded=None,
-                 return_logits=False, return_state=False, **other):
+                 return_logits=False, return_state=False, return_attention=False,
+                 return_last_attention=False, initial_state=None, **other):
         """inputs: [B, <=3000, n_mels] mel windows; tokens: [B, S] prompt ids.  Unknown keyword
         arguments (lang, verbose, ...) are ignored, as the reference's runtimes do.
         A `temperature` switches token selection from argmax / top-k to categorical draws, as in
@@ -196,11 +197,17 @@ class MI355XRuntime(Runtime):
         reference's own Whisper filter runs inside the device loop, anything else (and
         `return_logits` under beam search) runs the loop in Python, one cached decoder step per token,
         with the scores as CUDA tensors and the remaining keyword arguments of this call passed on
-        to the filter as the reference does (generation_utils.py:360-366, 518-520).  `return_state` is
-        refused: the decoder state is the engine's own K/V cache, which has no meaning outside it."""
-        if return_state:
-            raise ValueError('return_state: the K/V cache stays inside the engine (call the runtime '
-                             'again with the extended prompt instead)')
+        to the filter as the reference does (generation_utils.py:360-366, 518-520).
+        `return_attention` / `return_last_attention` fill `InferenceOutput.attention_weights` with the
+        dict {'attn_layer_<i>', 'enc_attn_layer_<i>'} of every / the last decoder layer, `return_state`
+        fills `.state` with a mapping layer name -> ((k, v), (enc_k, enc_v)) (eager.EngineState), and
+        `initial_state` = such a state, untouched since, continues from it: `inputs` may then be None
+        (the windows are the ones already encoded) and `tokens` are only the tokens that follow
+        (generation_utils.py:84-87, 186, 293-300).  These run the loop in Python as well."""
+        if initial_state is not None:
+            return self._continue(initial_state, tokens, tokens_length, max_length, max_new_tokens, method,
+                                  temperature, length_temperature, logits_filter, early_stopping, seed,
+                                  return_logits, return_state, return_attention, return_last_attention, other)
         if isinstance(inputs, torch.Tensor):
             mel = inputs
         else:
@@ -231,6 +238,7 @@ class MI355XRuntime(Runtime):
             eng = self.engine.get(max(b, self._max_batch), int(num_beams) if beam else 1, s + max_steps, s,
                                   replica=replica)
             self.engine._state_owner = None        # the encoded batch of an earlier encoder() call is gone
+            extras = {}
             eng.encode(mel)
             if on_encoded is not None:
                 ev = torch.cuda.Event()
@@ -242,10 +250,52 @@ class MI355XRuntime(Runtime):
                 early_stopping=early_stopping, temperature=temperature,
                 length_temperature=length_temperature, length_power=length_power,
                 logits_filter=logits_filter, seed=seed, return_logits=bool(return_logits),
-                filter_kwargs=other)
+                filter_kwargs=other, return_attention=bool(return_attention),
+                return_last_attention=bool(return_last_attention), return_state=bool(return_state),
+                extras=extras)
         toks, lengths, scores = out[:3]
         return InferenceOutput(tokens=toks, lengths=lengths, scores=scores,
-                               logits=out[3] if return_logits else None, state=None, attention_weights=None)
+                               logits=out[3] if return_logits else None, state=extras.get('state'),
+                               attention_weights=extras.get('attention_weights'))
+
+    def _continue(self, state, tokens, tokens_length, max_length, max_new_tokens, method, temperature,
+                  length_temperature, logits_filter, early_stopping, seed, return_logits, return_state,
+                  return_attention, return_last_attention, other):
+        """A loop that starts from the state an earlier call returned (`initial_state`): nothing is
+        encoded and no earlier token is run again; `max_length` counts the positions of the state."""
+        from ..eager import EngineState
+        if not isinstance(state, EngineState):
+            raise ValueError('initial_state must be the `state` of an earlier InferenceOutput of this runtime')
+        if tokens is None:
+            raise ValueError('initial_state needs the tokens that follow it')
+        tokens = np.asarray(tokens.cpu() if isinstance(tokens, torch.Tensor) else tokens, dtype=np.int32)
+        if tokens.ndim == 1:
+            tokens = np.tile(tokens[None], [state.n_seq, 1])
+        s = int(tokens_length) if tokens_length is not None else tokens.shape[1]
+        tokens = np.ascontiguousarray(tokens[:, :s])
+        if max_length is None:
+            max_length = state.length + s + (256 if max_new_tokens is None else int(max_new_tokens))
+        max_steps = int(max_length) - s - state.length
+        if max_steps < 1:
+            raise ValueError('state of {} positions and {} new tokens leave no room under max_length = {}'.format(
+                state.length, s, max_length))
+        eng = state.engine
+        if state.length + s + max_steps > eng.max_text_len:
+            raise ValueError('the engine was sized for {} positions; ask for the whole length in the first call '
+                             '(max_length)'.format(eng.max_text_len))
+        pad = self.pad_token if self.pad_token not in (-1, None) else self.eos_token
+        extras = {}
+        with self.engine.lock():
+            out = eng.generate(
+                tokens, method=method, max_new_tokens=max_steps, eos_token=self.eos_token, pad_token=pad,
+                early_stopping=early_stopping, temperature=temperature, length_temperature=length_temperature,
+                logits_filter=logits_filter, seed=seed, return_logits=bool(return_logits), filter_kwargs=other,
+                return_attention=bool(return_attention), return_last_attention=bool(return_last_attention),
+                return_state=bool(return_state), initial_state=state, extras=extras)
+        toks, lengths, scores = out[:3]
+        return InferenceOutput(tokens=toks, lengths=lengths, scores=scores,
+                               logits=out[3] if return_logits else None, state=extras.get('state'),
+                               attention_weights=extras.get('attention_weights'))
 
     # -- callables used by detect_language --------------------------------
     def encoder(self, mel, training=False, **_):

@@ -267,3 +267,134 @@ def test_ended_windows_are_skipped_without_changing_results(small):
     assert full[1].tolist() == [at, 16, 16]
     for a, b in zip(full, skip):
         assert np.array_equal(a, b)
+
+
+def test_attention_weights_against_oracle(small):
+    """stt_decode_step_attention: the weights of every decoder layer for the prompt pass and for
+    single-token steps are the oracle's softmax(q k^T / 8): within 5e-3 + 5 % of the oracle that
+    rounds to bf16 where the engine does, and within 0.1 absolute of the float32 oracle (the peaked
+    test weights give scores of tens of units, on which the 0.4 % of bf16 q and k move a weight of
+    0.5 by several hundredths from the second layer on: storage noise, as the rounding oracle shows); rows sum to one, entries past a token's own
+    position are zero, and asking for the weights changes no logit bit of a single-token step."""
+    dims, engine, oracle, mel, enc = small
+    engine.encode(mel)
+    toks = np.random.default_rng(5).integers(0, 998, size=(3, 6)).astype(np.int32)
+    rounded = om.Whisper(dims, oracle.w, round_acts=True)
+    with torch.no_grad():
+        _, _, ref = oracle.decoder(torch.from_numpy(toks).long(), oracle.cross_kv(enc), return_attention=True)
+        _, _, ref_r = rounded.decoder(torch.from_numpy(toks).long(), rounded.cross_kv(enc), return_attention=True)
+
+    def close(got, key, index):
+        got = got.cpu().numpy()
+        assert np.abs(got - ref[key][index].numpy()).max() < 0.1
+        want = ref_r[key][index].numpy()
+        assert (np.abs(got - want) - 0.05 * want).max() < 5e-3
+
+    plain = [engine.decode_step(toks[:, :3], reset=True)] + [engine.decode_step(toks[:, j: j + 1]) for j in (3, 4, 5)]
+    lg, own, cross = engine.decode_step(toks[:, :3], reset=True, attention="all")
+    assert own.shape == (2, 3, 2, 3, 3) and cross.shape == (2, 3, 2, 3, 1500)
+    # 3 queries per window: the plain pass runs the matrix-core cross-attention kernel, the pass that
+    # returns weights the vector-unit one (same sums in another order)
+    assert P.rel_l2(lg.cpu().numpy(), plain[0].cpu().numpy()) < 1e-2
+    for layer in range(2):
+        close(own[layer], "attn_layer_%d" % layer, (slice(None), slice(None), slice(0, 3), slice(0, 3)))
+        close(cross[layer], "enc_attn_layer_%d" % layer, (slice(None), slice(None), slice(0, 3)))
+    assert float(own[:, :, :, 0, 1:].abs().max()) == 0.0 and float(own[:, :, :, 1, 2].abs().max()) == 0.0
+    engine.decode_step(toks[:, :3], reset=True)      # the history of `plain` again (its prompt pass included)
+    for j in (3, 4, 5):
+        lg, own, cross = engine.decode_step(toks[:, j: j + 1], attention="all")
+        assert torch.equal(lg, plain[j - 2])
+        assert own.shape == (2, 3, 2, 1, j + 1)
+        for layer in range(2):
+            close(own[layer, :, :, 0], "attn_layer_%d" % layer, (slice(None), slice(None), j, slice(0, j + 1)))
+            close(cross[layer, :, :, 0], "enc_attn_layer_%d" % layer, (slice(None), slice(None), j))
+        assert np.abs(own.sum(-1).cpu().numpy() - 1).max() < 1e-4 and np.abs(cross.sum(-1).cpu().numpy() - 1).max() < 1e-4
+    lg, own, cross = engine.decode_step(toks[:, :1], attention="last")       # 'last' = the last layer only
+    assert own.shape[0] == 1 and cross.shape[0] == 1
+
+
+def test_exported_state_against_oracle_cache(small):
+    """stt_engine_export_state: the self-attention cache after a few steps and the encoder-attention
+    K/V are the oracle's (bf16 storage: 1e-2 relative)."""
+    dims, engine, oracle, mel, enc = small
+    engine.encode(mel)
+    toks = np.random.default_rng(6).integers(0, 998, size=(3, 5)).astype(np.int32)
+    with torch.no_grad():
+        cross = oracle.cross_kv(enc)
+        _, cache = oracle.decoder(torch.from_numpy(toks).long(), cross)
+    engine.decode_step(toks[:, :3], reset=True)
+    engine.decode_step(toks[:, 3:4])
+    engine.decode_step(toks[:, 4:5])
+    assert engine.step_state() == (3, 1, 5)
+    for layer in range(2):
+        (k, v), (ek, ev) = engine.export_state(layer)
+        assert k.shape == (3, 2, 5, 64) and ek.shape == (3, 2, 1500, 64)
+        assert P.rel_l2(k.cpu().numpy(), cache[layer][0].numpy()) < 1e-2
+        assert P.rel_l2(v.cpu().numpy(), cache[layer][1].numpy()) < 1e-2
+        assert P.rel_l2(ek.cpu().numpy(), cross[layer][0].numpy()) < 1e-2
+        assert P.rel_l2(ev.cpu().numpy(), cross[layer][1].numpy()) < 1e-2
+
+
+def test_runtime_state_attention_and_continuation():
+    """`return_state`, `return_last_attention`, `return_attention` and `initial_state` through the
+    Runtime call (generation_utils.py:84-87, 293-300): the ids are those of the plain call; a loop
+    continued from the returned state produces the ids the uninterrupted loop produces; a state that
+    the engine has moved past is refused."""
+    from speech_to_text_amd.runtimes import build_runtime
+    rt = build_runtime("mi355x", path="random:tiny:3:peaked")
+    rt.set_tokens(sos_token=50258, eos_token=50257, pad_token=50257)
+    mel = torch.rand(2, 3000, 80, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    prompt = np.array([[50258, 50259, 50359]] * 2)
+    whole = rt(mel, tokens=prompt, max_new_tokens=10, early_stopping=False)
+    first = rt(mel, tokens=prompt, max_new_tokens=6, early_stopping=False, return_state=True,
+               return_last_attention=True)
+    assert np.array_equal(first.tokens, whole.tokens[:, :6])
+    layers = rt.dims["n_text_layer"]
+    att = first.attention_weights
+    assert sorted(att) == ["attn_layer_%d" % (layers - 1), "enc_attn_layer_%d" % (layers - 1)]
+    heads = rt.dims["n_text_head"]
+    assert att["attn_layer_%d" % (layers - 1)].shape == (2, heads, 8, 8)          # 3 + 5 tokens fed
+    assert att["enc_attn_layer_%d" % (layers - 1)].shape == (2, heads, 8, 1500)
+    assert float((att["enc_attn_layer_%d" % (layers - 1)].sum(-1) - 1).abs().max()) < 1e-4
+    st = first.state
+    assert len(st) == layers and st.length == 8 and st.valid()
+    (k, v), (ek, ev) = st["layer_0"]
+    assert k.shape == (2, heads, 8, 64) and ek.shape == (2, heads, 1500, 64)
+    rest = rt(None, tokens=first.tokens[:, -1:], initial_state=st, max_new_tokens=4, early_stopping=False)
+    assert np.array_equal(rest.tokens, whole.tokens[:, 6:10])
+    assert not st.valid()
+    with pytest.raises(ValueError):
+        rt(None, tokens=first.tokens[:, -1:], initial_state=st, max_new_tokens=2)
+    with pytest.raises(RuntimeError):
+        st["layer_0"]
+    every = rt(mel, tokens=prompt, max_new_tokens=3, early_stopping=False, return_attention=True)
+    assert len(every.attention_weights) == 2 * layers
+    assert np.array_equal(every.tokens, whole.tokens[:, :3])
+
+
+def test_beam_attention_follows_the_beam_index(small):
+    """Under beam search the accumulated weights are gathered by the beam index at every step
+    (generation_utils.py:580-587): the rows returned for a final beam are those of one teacher-forced
+    pass over that beam's own tokens."""
+    from speech_to_text_amd import eager
+    dims, engine, oracle, mel, enc = small
+    engine.encode(mel)
+    extras = {}
+    toks, lens, scs = eager.generate(engine, PROMPT, method="beam", num_beams=3, num_sentences=3, max_new_tokens=5,
+                                     eos_token=EOS, pad_token=PAD, early_stopping=False, return_last_attention=True,
+                                     return_state=True, extras=extras)
+    att = extras["attention_weights"]
+    assert att["attn_layer_1"].shape == (9, 2, 7, 7) and att["enc_attn_layer_1"].shape == (9, 2, 7, 1500)
+    (k, v), _ = extras["state"]["layer_1"]
+    assert k.shape == (9, 2, 7, 64)
+    fed = np.concatenate([np.repeat(PROMPT, 3, axis=0), toks.reshape(9, 5)[:, :4]], axis=1).astype(np.int32)
+    engine.encode(mel)
+    _, own, cross = engine.decode_step(fed, seq_per_window=3, reset=True, attention="last")
+    # (one pass over 7 tokens against 5 passes: other GEMM and attention kernels fill the cache, and the
+    # peaked weights amplify their rounding as in test_attention_weights_against_oracle)
+    for got, want in ((att["attn_layer_1"], own[0]), (att["enc_attn_layer_1"], cross[0])):
+        assert float(((got - want).abs() - 0.05 * want).max()) < 5e-3
+    # ... while the beams of a window do differ by more than that, so a wrong gather would show
+    assert float((att["attn_layer_1"][0] - att["attn_layer_1"][1]).abs().max()) > 2e-2
+    (k2, v2), _ = engine.export_state(1)
+    assert P.rel_l2(k.cpu().numpy(), k2.cpu().numpy()) < 1e-2 and P.rel_l2(v.cpu().numpy(), v2.cpu().numpy()) < 1e-2
