@@ -170,3 +170,32 @@ def test_bf16_storage_noise_floor():
     rel_e = float((e1 - e0).norm() / e0.norm())
     rel_l = float((l1 - l0).norm() / l0.norm())
     assert 2e-4 < rel_e < 1e-2 and 5e-4 < rel_l < 2e-2, (rel_e, rel_l)
+
+
+def test_attention_weights_match_transformers():
+    """The oracle's `return_attention` dict (what the attention-weight outputs of the HIP decoder are
+    checked against) equals transformers' decoder_attentions / cross_attentions on the same weights."""
+    dims = om.Dims(n_mels=80, n_audio_ctx=100, n_audio_state=64, n_audio_head=2, n_audio_layer=2,
+                   n_vocab=300, n_text_ctx=32, n_text_state=64, n_text_head=2, n_text_layer=2)
+    w = om.random_weights(dims, seed=4)
+    model = om.Whisper(dims, w, gelu_approximate="none")
+    hf = _hf_from_oracle(dims, w, "gelu")
+    hf.config._attn_implementation = "eager"
+    g = torch.Generator().manual_seed(1)
+    mel = torch.randn(2, 200, 80, generator=g)
+    tokens = torch.randint(0, 300, (2, 6), generator=g)
+    with torch.no_grad():
+        enc = model.encoder(mel)
+        _, _, att = model.decoder(tokens, model.cross_kv(enc), return_attention=True)
+        out = hf(decoder_input_ids=tokens, encoder_outputs=(enc,), output_attentions=True)
+    if not out.decoder_attentions or out.decoder_attentions[0] is None:
+        pytest.skip("this transformers build does not return attention weights")
+    for i in range(dims.n_text_layer):
+        assert torch.allclose(att["attn_layer_%d" % i], out.decoder_attentions[i], atol=1e-5)
+        assert torch.allclose(att["enc_attn_layer_%d" % i], out.cross_attentions[i], atol=1e-5)
+    # incremental: the row of a single cached step is the last row of the full pass
+    with torch.no_grad():
+        _, c1 = model.decoder(tokens[:, :5], model.cross_kv(enc))
+        _, _, a2 = model.decoder(tokens[:, 5:6], model.cross_kv(enc), c1, 5, return_attention=True)
+    assert torch.allclose(a2["attn_layer_1"][:, :, 0], att["attn_layer_1"][:, :, 5], atol=1e-5)
+    assert torch.allclose(a2["enc_attn_layer_1"][:, :, 0], att["enc_attn_layer_1"][:, :, 5], atol=1e-5)
