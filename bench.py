@@ -107,10 +107,20 @@ def init_dist(backend):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        # the backends' native code may greet on stdout (gloo prints its peer count): stdout is kept for
+        # the one JSON line, so it points at stderr while the group forms
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
         world = dist.get_world_size()
     return rank, world, local
 
