@@ -234,6 +234,7 @@ void launch_greedy_step(const GenState& s, const FilterArgs& f, const LogitParam
 // and the `beams` best entries of the row (ties to the lowest token id), which is all the
 // per-window selection needs: within a row the length penalty is one positive factor.
 #define BEAM_MAX 16
+#define BEAM_KEEP 8       // candidates a thread keeps in registers during the one-pass selection
 __global__ __launch_bounds__(256) void beam_logprob_kernel(const GenState s, const FilterArgs f,
                                                            const LogitParams p, int n_vocab,
                                                            int max_steps, int pad, int beams) {
@@ -247,6 +248,44 @@ __global__ __launch_bounds__(256) void beam_logprob_kernel(const GenState s, con
   row_stats(row, m, sh, shi, mx, arg, lse);
   const float base = s.scores[i];
   const bool fin = s.finished[i];
+  if (!p.sample && beams <= BEAM_KEEP) {
+    // One pass writes the row and keeps, per thread, the BEAM_KEEP best of the entries it wrote
+    // (sorted: value descending, token id ascending - a thread meets its ids in ascending order,
+    // so an equal later value never moves ahead of an earlier one).  The block then takes the best
+    // head `beams` times; the thread that owned it moves its list up.  Same order as the
+    // pass-per-winner loop below, one read of the row instead of `beams`.
+    float tv[BEAM_KEEP];
+    int ti[BEAM_KEEP];
+#pragma unroll
+    for (int k = 0; k < BEAM_KEEP; ++k) { tv[k] = NEG_INF; ti[k] = 0x7fffffff; }
+    for_row(row, 0, n_vocab, [&](int j, float x) {
+      float v;
+      if (fin) v = j == pad ? 0.f : NEG_INF;
+      else v = (j < m.lo || j >= m.hi) ? NEG_INF : x - lse;
+      v = base + v;
+      row[j] = v;
+      if (v > tv[BEAM_KEEP - 1]) {
+        tv[BEAM_KEEP - 1] = v; ti[BEAM_KEEP - 1] = j;
+#pragma unroll
+        for (int k = BEAM_KEEP - 1; k > 0; --k)
+          if (tv[k] > tv[k - 1]) {
+            const float fv = tv[k]; tv[k] = tv[k - 1]; tv[k - 1] = fv;
+            const int fi = ti[k]; ti[k] = ti[k - 1]; ti[k - 1] = fi;
+          }
+      }
+    });
+    for (int sel = 0; sel < beams; ++sel) {
+      float bm = tv[0]; int ba = ti[0];
+      block_argmax(bm, ba, sh, shi);
+      if (tid == 0) { s.row_val[i * BEAM_MAX + sel] = bm; s.row_idx[i * BEAM_MAX + sel] = ba; }
+      if (ba != 0x7fffffff && ti[0] == ba) {
+#pragma unroll
+        for (int k = 0; k + 1 < BEAM_KEEP; ++k) { tv[k] = tv[k + 1]; ti[k] = ti[k + 1]; }
+        tv[BEAM_KEEP - 1] = NEG_INF; ti[BEAM_KEEP - 1] = 0x7fffffff;
+      }
+    }
+    return;
+  }
   for_row(row, 0, n_vocab, [&](int j, float x) {
     float v;
     if (fin) v = j == pad ? 0.f : NEG_INF;
