@@ -221,6 +221,22 @@ def test_beam_search(small):
             assert abs(want - scores[b, 0]) < 0.3
 
 
+def test_beam_search_ten_beams(small):
+    """More beams than a thread keeps in registers during the one-pass selection (8): the
+    pass-per-winner selection takes over; every transition against the oracle, an EOS in reach."""
+    dims, engine, oracle, mel = small
+    engine.reserve(max_beams=10)
+    engine.encode(mel)
+    prompt = np.array([[1, 2, 3]] * 3, dtype=np.int32)
+    free, _, _ = engine.generate(prompt, method="beam", num_beams=10, num_sentences=1, max_new_tokens=6,
+                                 eos_token=999, pad_token=999, early_stopping=False)
+    eos = int(free[0, 0, 2])
+    with torch.no_grad():
+        enc = oracle.encoder(mel)
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 10, 6, eos, 0) == 18
+        assert P.check_beam_steps(engine, oracle, enc, prompt, 8, 6, eos, 0) == 18
+
+
 def test_beam_search_length_power(small):
     """`length_power` (generation_utils.py:372-374): candidates ranked by score / (length + 1) ** p,
     with an EOS that beams do reach so that lengths differ between beams."""
