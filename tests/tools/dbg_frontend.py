@@ -1,5 +1,5 @@
 import numpy as np, torch, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import frontend as oracle
 from speech_to_text_amd.audio.stft import WhisperSTFT
 fn = WhisperSTFT()

@@ -1,7 +1,7 @@
 """Engine vs oracle teacher-forced logits on peaked weights: how large is the bf16 error in nats?"""
 import dataclasses, sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import model as om
 from tests import _parity as P
 from speech_to_text_amd.engine import WhisperEngine

@@ -2,7 +2,7 @@
 (exactly bin b of the 400-point frame), compared with the numpy oracle frame by frame."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import frontend as oracle
 from speech_to_text_amd.audio.stft import WhisperSTFT
 n_mels = int(sys.argv[1]) if len(sys.argv) > 1 else 80
