@@ -158,3 +158,22 @@ def test_large_v3_special_token_ids():
     assert v3.lang_to_idx["yue"] == 50358 and len(v3.lang_to_idx) == 100 and v3.lang_to_idx["en"] == 50259
     assert v3.start_of_prev_token_idx == 50362 and v3.notimestamps_idx == 50364
     assert v3.eos_token_idx == base.eos_token_idx == 50257 and v3.sos_token_idx == 50258
+
+
+def test_stft_configuration_round_trip(tmp_path):
+    """The reference's own test of its mel classes (tests/test_utils_audio.py:89-103): a saved
+    configuration loads back into an equal object, of the class its `class_name` states."""
+    from speech_to_text_amd.audio.stft import MelSTFT, WhisperSTFT
+    for fn in (WhisperSTFT(), WhisperSTFT(n_mel_channels=128)):
+        path = str(tmp_path / "WhisperSTFT.json")
+        fn.save(path)
+        assert os.path.exists(path)
+        back = MelSTFT.load_from_file(path)
+        assert type(back) is WhisperSTFT and back == fn and back.get_config() == fn.get_config()
+        assert MelSTFT.create(path) == fn
+    assert WhisperSTFT() != WhisperSTFT(n_mel_channels=128)
+    # the reference's length estimate, ceil(max(filter_length, n) / hop_length) (utils/audio/stft.py:122-127):
+    # an upper bound used for padding, not the frame count of the transform (404 frames for 64 880 samples)
+    fn = WhisperSTFT()
+    assert [fn.get_mel_length(n) for n in (399, 400, 559, 560, 64880)] == [3, 3, 4, 4, 406]
+    assert fn.get_audio_length(406) == 64960
